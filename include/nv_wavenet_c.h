@@ -1,0 +1,78 @@
+/*
+ * nv_wavenet_c.h -- C ABI onto every nvWavenetInfer<T_weight,T_data,R,S,A> instantiation that
+ * libwavenet_infer.so carries.  One handle = one engine object; each call maps 1:1 onto the
+ * member of the same name of the reference class (/root/reference/nv_wavenet.cuh:220-640):
+ *
+ *   nvw_create            <- nvWavenetInfer(numLayers, maxDilation, batchSize, numSamples, impl,
+ *                                           tanhEmbed)                        nv_wavenet.cuh:311
+ *   nvw_set_embeddings    <- setEmbeddings                                   nv_wavenet.cuh:396-399
+ *   nvw_set_layer_weights <- setLayerWeights                                 nv_wavenet.cuh:400-409
+ *   nvw_set_out_weights   <- setOutWeights                                   nv_wavenet.cuh:410-415
+ *   nvw_set_inputs        <- setInputs                                       nv_wavenet.cuh:417-422
+ *   nvw_run / nvw_run_partial / nvw_run_chunks <- run / run_partial / run_chunks
+ *                                                                            nv_wavenet.cuh:445-639
+ *   nvw_get_*             <- getXtOut/getSkipOut/getZs/getZa/getP/getYOut    nv_wavenet.cuh:424-444
+ *
+ * The reference has no such header: its only FFI is pytorch/wavenet_infer.h, which hard-wires one
+ * instantiation (see include/wavenet_infer.h).  This one exists so that non-C++ hosts (Python
+ * ctypes, tests, bench.py) can reach fp16, other channel counts, chunked streaming and the
+ * debug getters without a compiler.  Plain pointers and ints only; `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  Pointers may be host or device memory wherever the
+ * reference accepts both.  Precision is 32 (<float,float>) or 16 (<half2,half>).
+ *
+ * Errors: unsupported (R,S,A,precision) -> nvw_create returns NULL; run calls return 1 on
+ * success and 0 when the launch failed (the reference's bool); HIP failures print
+ * "GPUassert: ..." and exit like the reference's gpuErrChk.
+ */
+#ifndef NV_WAVENET_C_H
+#define NV_WAVENET_C_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nvw_engine nvw_engine;
+
+/* consumer callback of nvw_run_chunks: (yOut, first sample of the chunk, samples in it, user) */
+typedef void (*nvw_consume_fn)(int* yOut, int init_sample, int count, void* user);
+
+int nvw_supported(int R, int S, int A, int precision);
+/* writes up to `max` (R,S,A,precision) quadruples into out[4*i..], returns how many exist */
+int nvw_list_supported(int* out, int max);
+
+nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int max_dilation,
+                       int batch_size, int num_samples, int implementation, int tanh_embed);
+void nvw_destroy(nvw_engine* e);
+
+void nvw_set_embeddings(nvw_engine* e, float* embed_prev, float* embed_cur);
+void nvw_set_layer_weights(nvw_engine* e, int layer, float* Wprev, float* Wcur, float* Bh,
+                           float* Wres, float* Bres, float* Wskip, float* Bskip);
+void nvw_set_out_weights(nvw_engine* e, float* Wzs, float* Bzs, float* Wza, float* Bza);
+void nvw_set_inputs(nvw_engine* e, float* Lh, float* output_selectors);
+
+int nvw_run(nvw_engine* e, int num_samples, int batch_size, int* yOut, int batch_size_per_block,
+            int dump_activations, void* stream);
+int nvw_run_partial(nvw_engine* e, int init_sample, int num_samples, int batch_size, int* yOut,
+                    int batch_size_per_block, int dump_activations, void* stream);
+int nvw_run_chunks(nvw_engine* e, int num_samples_per_chunk, nvw_consume_fn consume, void* user,
+                   int num_samples, int batch_size, int* yOut, int batch_size_per_block,
+                   int dump_activations, void* stream);
+
+void nvw_get_xt_out(nvw_engine* e, int layer, float* dst);     /* [maxBatch][R] */
+void nvw_get_skip_out(nvw_engine* e, int layer, float* dst);   /* [maxBatch][S] */
+void nvw_get_zs(nvw_engine* e, float* dst);                    /* [maxBatch][A] */
+void nvw_get_za(nvw_engine* e, float* dst);                    /* [maxBatch][A] */
+void nvw_get_p(nvw_engine* e, float* dst);                     /* [maxBatch][A] */
+void nvw_get_y_out(nvw_engine* e, int* yOut, int offset, int size, void* stream);
+
+/* hipDeviceSynchronize() for hosts without a HIP binding */
+void nvw_device_synchronize(void);
+/* time `reps` back-to-back nvw_run() launches with HIP events on `stream`; returns milliseconds
+ * for all reps (used by bench.py: events on the stream the kernel is launched on) */
+float nvw_time_runs(nvw_engine* e, int reps, int num_samples, int batch_size, int batch_size_per_block,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

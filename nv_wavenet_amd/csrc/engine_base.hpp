@@ -1,0 +1,58 @@
+// engine_base.hpp -- type-erased door onto nvWavenetInfer<...> instantiations for the C ABI
+// (include/nv_wavenet_c.h).  One translation unit per instantiation (engine_inst.hip) so the
+// big kernel templates compile in parallel.
+#pragma once
+#include "../../include/nv_wavenet_c.h"
+#include "nv_wavenet.hpp"
+
+struct nvw_engine {
+    virtual ~nvw_engine() {}
+    virtual void setEmbeddings(float*, float*) = 0;
+    virtual void setLayerWeights(int, float*, float*, float*, float*, float*, float*, float*) = 0;
+    virtual void setOutWeights(float*, float*, float*, float*) = 0;
+    virtual void setInputs(float*, float*) = 0;
+    virtual bool run(int, int, int*, int, bool, hipStream_t) = 0;
+    virtual bool run_partial(int, int, int, int*, int, bool, hipStream_t) = 0;
+    virtual bool run_chunks(int, nvw_consume_fn, void*, int, int, int*, int, bool, hipStream_t) = 0;
+    virtual void getXtOut(int, float*) = 0;
+    virtual void getSkipOut(int, float*) = 0;
+    virtual void getZs(float*) = 0;
+    virtual void getZa(float*) = 0;
+    virtual void getP(float*) = 0;
+    virtual void getYOut(int*, int, int, hipStream_t) = 0;
+};
+
+template <typename Tw, typename Td, int R, int S, int A>
+struct EngineImpl : nvw_engine {
+    nvWavenetInfer<Tw, Td, R, S, A> eng;
+    EngineImpl(int L, int maxD, int B, int N, int impl, bool tanhEmbed) : eng(L, maxD, B, N, impl, tanhEmbed) {}
+    void setEmbeddings(float* p, float* c) override { eng.setEmbeddings(p, c); }
+    void setLayerWeights(int l, float* a, float* b, float* c, float* d, float* e, float* f, float* g) override {
+        eng.setLayerWeights(l, a, b, c, d, e, f, g);
+    }
+    void setOutWeights(float* a, float* b, float* c, float* d) override { eng.setOutWeights(a, b, c, d); }
+    void setInputs(float* Lh, float* sel) override { eng.setInputs(Lh, sel); }
+    bool run(int n, int b, int* y, int bspb, bool dump, hipStream_t s) override {
+        return eng.run(n, b, y, bspb, dump, s);
+    }
+    bool run_partial(int i, int n, int b, int* y, int bspb, bool dump, hipStream_t s) override {
+        return eng.run_partial(i, n, b, y, bspb, dump, s);
+    }
+    bool run_chunks(int chunk, nvw_consume_fn fn, void* user, int n, int b, int* y, int bspb, bool dump,
+                    hipStream_t s) override {
+        return eng.run_chunks(chunk, [fn, user](int* yo, int i, int c) { if (fn) fn(yo, i, c, user); }, n, b, y,
+                              bspb, dump, s);
+    }
+    void getXtOut(int l, float* d) override { eng.getXtOut(l, d); }
+    void getSkipOut(int l, float* d) override { eng.getSkipOut(l, d); }
+    void getZs(float* d) override { eng.getZs(d); }
+    void getZa(float* d) override { eng.getZa(d); }
+    void getP(float* d) override { eng.getP(d); }
+    void getYOut(int* y, int off, int size, hipStream_t s) override { eng.getYOut(y, off, size, s); }
+};
+
+typedef nvw_engine* (*nvw_factory_fn)(int L, int maxD, int B, int N, int impl, int tanhEmbed);
+
+#define WN_CAT2(a, b) a##b
+#define WN_CAT(a, b) WN_CAT2(a, b)
+#define WN_FACTORY_NAME(R, S, A, P) WN_CAT(WN_CAT(WN_CAT(WN_CAT(WN_CAT(WN_CAT(WN_CAT(nvw_make_, R), _), S), _), A), _p), P)

@@ -1,0 +1,391 @@
+// nv_wavenet.hpp -- host engine: nvWavenetInfer<T_weight, T_data, R, S, A> for MI355X (gfx950).
+//
+// Drop-in for the class of the same name in /root/reference/nv_wavenet.cuh:220-640: same template
+// parameters, Implementation enum values, constructor, setEmbeddings / setLayerWeights /
+// setOutWeights / setInputs, run / run_partial / run_chunks and debug getters, with the same
+// argument meaning, layouts (col-major fp32 weights in, host OR device pointers, data copied),
+// defaults and error convention (HIP errors print "GPUassert: ..." and exit, precondition
+// violations assert, nv_wavenet_util.cuh:34-40).  Streams are hipStream_t.
+//
+// What is different underneath (see wn_kernels.hpp): all Implementation values run the
+// wave-per-16-utterances MFMA engine; batch_size_per_block is validated like the reference
+// (nv_wavenet.cuh:559-561) but the batch tile is fixed by the MFMA shape (16 utterances per
+// wavefront), so it is a no-op hint.  Device buffers are laid out for that engine, not for the
+// reference's kernels; the getters return the reference's layouts.
+#pragma once
+
+#include <assert.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+#include <vector>
+
+#include "wn_kernels.hpp"
+
+#ifndef gpuErrChk
+#define gpuErrChk(ans) { wnGpuAssert((ans), __FILE__, __LINE__); }
+inline void wnGpuAssert(hipError_t code, const char* file, int line, bool abort = true) {
+    if (code != hipSuccess) {
+        fprintf(stderr, "GPUassert: %s %s %d\n", hipGetErrorString(code), file, line);
+        if (abort) exit(code);
+    }
+}
+#endif
+
+template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
+class nvWavenetInfer {
+public:
+    enum Implementation { AUTO = 0, SINGLE_BLOCK, DUAL_BLOCK, PERSISTENT, MANYBLOCK_NONPERSISTENT };
+
+    static constexpr bool F16 = !std::is_same<T_data, float>::value;
+    static_assert(std::is_same<T_data, float>::value || std::is_same<T_data, half>::value,
+                  "T_data must be float or half");
+    static_assert(std::is_same<T_weight, float>::value == std::is_same<T_data, float>::value,
+                  "T_weight/T_data must be <float,float> or <half2,half>");
+
+protected:
+    using C = wn::Cfg<F16, R, S, A>;
+    using elem = typename wn::Prec<F16>::elem;
+
+    Implementation m_implementation;
+    int m_numLayers, m_maxBatch, m_maxSamples, m_maxDilation, m_groups;
+    bool m_tanhEmbed;
+    int m_num_samples_per_chunk;
+    int m_ringSlots;
+
+    elem* m_wblob;      // packed weight fragments: L layers then the head
+    float* m_bias;      // fp32 biases
+    elem* m_embedPrev;  // [A][R]
+    elem* m_embedCur;
+    elem* m_cond;       // packed conditioning
+    float* m_outputSelectors;
+    elem* m_ring;
+    int *m_dil, *m_ringOff;
+    int *m_yInPrev, *m_yInCur, *m_yOut;
+    float *m_XtOut, *m_skipOut, *m_Zs, *m_Za, *m_p;
+
+    float* m_stage;     // device staging for fp32 uploads from host pointers
+    size_t m_stageElems;
+
+    static bool isDevicePtr(const void* ptr) {
+        hipPointerAttribute_t attr;
+        hipError_t e = hipPointerGetAttributes(&attr, ptr);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+    }
+    // returns a device pointer holding n floats of src (src itself when already on the device)
+    const float* onDevice(const float* src, size_t n) {
+        if (isDevicePtr(src)) return src;
+        if (n > m_stageElems) {
+            if (m_stage) gpuErrChk(hipFree(m_stage));
+            gpuErrChk(hipMalloc(&m_stage, n * sizeof(float)));
+            m_stageElems = n;
+        }
+        gpuErrChk(hipMemcpy(m_stage, src, n * sizeof(float), hipMemcpyHostToDevice));
+        return m_stage;
+    }
+    static int gridFor(size_t n) {
+        size_t g = (n + 255) / 256;
+        return (int)(g > 4096 ? 4096 : (g ? g : 1));
+    }
+    void packWeight(elem* dst, const float* src, int M, int K, int rowperm) {
+        const float* d = onDevice(src, (size_t)M * K);
+        hipLaunchKernelGGL((wn::pack_weight_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0, dst, d, M, K,
+                           rowperm);
+        gpuErrChk(hipGetLastError());
+        gpuErrChk(hipStreamSynchronize(0));
+    }
+    void convertTo(elem* dst, const float* src, size_t n) {
+        const float* d = onDevice(src, n);
+        hipLaunchKernelGGL((wn::convert_kernel<F16>), dim3(gridFor(n)), dim3(256), 0, 0, dst, d, n);
+        gpuErrChk(hipGetLastError());
+        gpuErrChk(hipStreamSynchronize(0));
+    }
+    elem* layerBlob(int layer) { return m_wblob + (size_t)layer * C::FL * 64 * C::EPL; }
+    elem* headBlob() { return layerBlob(m_numLayers); }
+    float* headBias() { return m_bias + (size_t)m_numLayers * C::BIAS_L; }
+
+public:
+    nvWavenetInfer(int numLayers, int maxDilation, int batchSize, int numSamples, int impl = 0,
+                   bool tanhEmbed = true)
+        : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
+          m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
+          m_num_samples_per_chunk(0), m_stage(NULL), m_stageElems(0) {
+        assert(numLayers > 0 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
+        m_groups = (batchSize + 15) / 16;
+
+        // dilation schedule (nv_wavenet.cuh:99,110-111): d doubles per layer, back to 1 past maxDilation
+        std::vector<int> dil(numLayers), off(numLayers);
+        int d = 1, slots = 0;
+        for (int l = 0; l < numLayers; l++) {
+            dil[l] = d;
+            off[l] = slots;
+            slots += d;
+            d <<= 1;
+            if (d > maxDilation) d = 1;
+        }
+        m_ringSlots = slots;
+        gpuErrChk(hipMalloc(&m_dil, numLayers * sizeof(int)));
+        gpuErrChk(hipMalloc(&m_ringOff, numLayers * sizeof(int)));
+        gpuErrChk(hipMemcpy(m_dil, dil.data(), numLayers * sizeof(int), hipMemcpyHostToDevice));
+        gpuErrChk(hipMemcpy(m_ringOff, off.data(), numLayers * sizeof(int), hipMemcpyHostToDevice));
+
+        const size_t wElems = ((size_t)numLayers * C::FL + C::FH) * 64 * C::EPL;
+        gpuErrChk(hipMalloc(&m_wblob, wElems * sizeof(elem)));
+        gpuErrChk(hipMemset(m_wblob, 0, wElems * sizeof(elem)));
+        const size_t bElems = (size_t)numLayers * C::BIAS_L + 2 * A;
+        gpuErrChk(hipMalloc(&m_bias, bElems * sizeof(float)));
+        gpuErrChk(hipMemset(m_bias, 0, bElems * sizeof(float)));
+        gpuErrChk(hipMalloc(&m_embedPrev, (size_t)A * R * sizeof(elem)));
+        gpuErrChk(hipMalloc(&m_embedCur, (size_t)A * R * sizeof(elem)));
+        gpuErrChk(hipMemset(m_embedPrev, 0, (size_t)A * R * sizeof(elem)));
+        gpuErrChk(hipMemset(m_embedCur, 0, (size_t)A * R * sizeof(elem)));
+
+        const size_t condElems = (size_t)numSamples * numLayers * m_groups * 16 * 2 * R;
+        gpuErrChk(hipMalloc(&m_cond, condElems * sizeof(elem)));
+        gpuErrChk(hipMemset(m_cond, 0, condElems * sizeof(elem)));
+        gpuErrChk(hipMalloc(&m_outputSelectors, (size_t)numSamples * batchSize * sizeof(float)));
+        gpuErrChk(hipMemset(m_outputSelectors, 0, (size_t)numSamples * batchSize * sizeof(float)));
+
+        const size_t ringElems = (size_t)m_groups * m_ringSlots * R * 16;
+        gpuErrChk(hipMalloc(&m_ring, ringElems * sizeof(elem)));
+        gpuErrChk(hipMemset(m_ring, 0, ringElems * sizeof(elem)));
+
+        gpuErrChk(hipMalloc(&m_yInPrev, batchSize * sizeof(int)));
+        gpuErrChk(hipMalloc(&m_yInCur, batchSize * sizeof(int)));
+        gpuErrChk(hipMalloc(&m_yOut, (size_t)numSamples * batchSize * sizeof(int)));
+        gpuErrChk(hipMemset(m_yOut, 0, (size_t)numSamples * batchSize * sizeof(int)));
+
+        gpuErrChk(hipMalloc(&m_XtOut, (size_t)numLayers * R * batchSize * sizeof(float)));
+        gpuErrChk(hipMalloc(&m_skipOut, (size_t)numLayers * S * batchSize * sizeof(float)));
+        gpuErrChk(hipMalloc(&m_Zs, (size_t)A * batchSize * sizeof(float)));
+        gpuErrChk(hipMalloc(&m_Za, (size_t)A * batchSize * sizeof(float)));
+        gpuErrChk(hipMalloc(&m_p, (size_t)A * batchSize * sizeof(float)));
+        gpuErrChk(hipMemset(m_XtOut, 0, (size_t)numLayers * R * batchSize * sizeof(float)));
+        gpuErrChk(hipMemset(m_skipOut, 0, (size_t)numLayers * S * batchSize * sizeof(float)));
+        gpuErrChk(hipMemset(m_Zs, 0, (size_t)A * batchSize * sizeof(float)));
+        gpuErrChk(hipMemset(m_Za, 0, (size_t)A * batchSize * sizeof(float)));
+        gpuErrChk(hipMemset(m_p, 0, (size_t)A * batchSize * sizeof(float)));
+
+        hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
+        gpuErrChk(hipGetLastError());
+
+        const size_t ldsBytes = bElems * sizeof(float);
+        gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wave16<F16, R, S, A>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        gpuErrChk(hipDeviceSynchronize());
+    }
+
+    virtual ~nvWavenetInfer() {
+        gpuErrChk(hipDeviceSynchronize());
+        gpuErrChk(hipFree(m_dil));
+        gpuErrChk(hipFree(m_ringOff));
+        gpuErrChk(hipFree(m_wblob));
+        gpuErrChk(hipFree(m_bias));
+        gpuErrChk(hipFree(m_embedPrev));
+        gpuErrChk(hipFree(m_embedCur));
+        gpuErrChk(hipFree(m_cond));
+        gpuErrChk(hipFree(m_outputSelectors));
+        gpuErrChk(hipFree(m_ring));
+        gpuErrChk(hipFree(m_yInPrev));
+        gpuErrChk(hipFree(m_yInCur));
+        gpuErrChk(hipFree(m_yOut));
+        gpuErrChk(hipFree(m_XtOut));
+        gpuErrChk(hipFree(m_skipOut));
+        gpuErrChk(hipFree(m_Zs));
+        gpuErrChk(hipFree(m_Za));
+        gpuErrChk(hipFree(m_p));
+        if (m_stage) gpuErrChk(hipFree(m_stage));
+    }
+
+    // ---- model upload: fp32 in, host or device pointers, data is copied ---------------------
+    // embedPrev / embedCur: [A][R]   (nv_wavenet.cuh:396-399)
+    virtual void setEmbeddings(float* embedPrev, float* embedCur) {
+        convertTo(m_embedPrev, embedPrev, (size_t)A * R);
+        convertTo(m_embedCur, embedCur, (size_t)A * R);
+    }
+    // col-major Wprev,Wcur 2RxR; Bh 2R; Wres RxR; Bres R; Wskip SxR; Bskip S (nv_wavenet.cuh:400-409)
+    virtual void setLayerWeights(int layer, float* Wprev, float* Wcur, float* Bh, float* Wres, float* Bres,
+                                 float* Wskip, float* Bskip) {
+        assert(layer >= 0 && layer < m_numLayers);
+        elem* blob = layerBlob(layer);
+        const size_t fe = (size_t)64 * C::EPL;  // elements per fragment
+        packWeight(blob + C::O_PREV * fe, Wprev, 2 * R, R, 0);
+        packWeight(blob + C::O_CUR * fe, Wcur, 2 * R, R, 0);
+        packWeight(blob + C::O_RES * fe, Wres, R, R, 0);
+        packWeight(blob + C::O_SKIP * fe, Wskip, S, R, 0);
+        float* b = m_bias + (size_t)layer * C::BIAS_L;
+        gpuErrChk(hipMemcpy(b, Bh, 2 * R * sizeof(float), hipMemcpyDefault));
+        gpuErrChk(hipMemcpy(b + 2 * R, Bres, R * sizeof(float), hipMemcpyDefault));
+        gpuErrChk(hipMemcpy(b + 3 * R, Bskip, S * sizeof(float), hipMemcpyDefault));
+    }
+    // col-major Wzs AxS, Bzs A, Wza AxA, Bza A (nv_wavenet.cuh:410-415)
+    virtual void setOutWeights(float* Wzs, float* Bzs, float* Wza, float* Bza) {
+        elem* blob = headBlob();
+        const size_t fe = (size_t)64 * C::EPL;
+        packWeight(blob, Wzs, A, S, 0);
+        packWeight(blob + C::F_ZS * fe, Wza, A, A, 1);  // lane-contiguous logit rows
+        gpuErrChk(hipMemcpy(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault));
+        gpuErrChk(hipMemcpy(headBias() + A, Bza, A * sizeof(float), hipMemcpyDefault));
+    }
+
+    // Lh: [maxSamples][L][maxBatch][2R] conditioning, outputSelectors: [maxSamples][maxBatch]
+    // uniform draws; resets the sample history to 128 (nv_wavenet.cuh:417-422).
+    void setInputs(float* Lh, float* outputSelectors) {
+        hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
+        gpuErrChk(hipGetLastError());
+        const size_t rows = (size_t)m_maxSamples * m_numLayers;
+        const size_t srcPerRow = (size_t)m_maxBatch * 2 * R;
+        const size_t dstPerRow = (size_t)m_groups * 16 * 2 * R;
+        const bool dev = isDevicePtr(Lh);
+        // host sources go through the staging buffer in chunks of <= 64 Mi floats
+        size_t chunkRows = dev ? rows : ((size_t)64 << 20) / srcPerRow;
+        if (chunkRows < 1) chunkRows = 1;
+        for (size_t r0 = 0; r0 < rows; r0 += chunkRows) {
+            const size_t nr = (rows - r0 < chunkRows) ? rows - r0 : chunkRows;
+            const float* src = onDevice(Lh + r0 * srcPerRow, nr * srcPerRow);
+            hipLaunchKernelGGL((wn::pack_cond_kernel<F16>), dim3(gridFor(nr * dstPerRow)), dim3(256), 0, 0,
+                               m_cond + r0 * dstPerRow, src, nr, m_maxBatch, m_groups, 2 * R);
+            gpuErrChk(hipGetLastError());
+            gpuErrChk(hipStreamSynchronize(0));
+        }
+        gpuErrChk(hipMemcpy(m_outputSelectors, outputSelectors, (size_t)m_maxSamples * m_maxBatch * sizeof(float),
+                            hipMemcpyDefault));
+    }
+
+    // ---- debug getters: last generated sample's activations, reference layouts --------------
+    void getXtOut(int layer, float* hXt) {
+        gpuErrChk(hipMemcpy(hXt, m_XtOut + (size_t)layer * m_maxBatch * R, (size_t)m_maxBatch * R * sizeof(float),
+                            hipMemcpyDefault));
+    }
+    void getSkipOut(int layer, float* hSkipOut) {
+        gpuErrChk(hipMemcpy(hSkipOut, m_skipOut + (size_t)layer * m_maxBatch * S,
+                            (size_t)m_maxBatch * S * sizeof(float), hipMemcpyDefault));
+    }
+    void getZs(float* hZs) { gpuErrChk(hipMemcpy(hZs, m_Zs, (size_t)m_maxBatch * A * sizeof(float), hipMemcpyDefault)); }
+    void getZa(float* hZa) { gpuErrChk(hipMemcpy(hZa, m_Za, (size_t)m_maxBatch * A * sizeof(float), hipMemcpyDefault)); }
+    void getP(float* hP) { gpuErrChk(hipMemcpy(hP, m_p, (size_t)m_maxBatch * A * sizeof(float), hipMemcpyDefault)); }
+    void getYOut(int* yOut, int offset, int size, hipStream_t stream = 0) {
+        size_t cpy_pitch = m_maxSamples * sizeof(int);  // spacing between chunk first elements
+        size_t cpy_width = size * sizeof(int);          // size of individual chunk
+        size_t cpy_height = m_maxBatch;
+        gpuErrChk(hipMemcpy2DAsync(yOut + offset, cpy_pitch, m_yOut + offset, cpy_pitch, cpy_width, cpy_height,
+                                   hipMemcpyDefault, stream));
+    }
+
+    // ---- generation --------------------------------------------------------------------------
+    // Streams chunks of num_samples_per_chunk samples; the copy of chunk j overlaps the compute of
+    // chunk j+1; consume(yOut, firstSample, count) runs on the host thread per finished chunk
+    // (nv_wavenet.cuh:445-497).
+    template <class Callback>
+    bool run_chunks(int num_samples_per_chunk, Callback consume, int num_samples, int batch_size, int* yOut = NULL,
+                    int batch_size_per_block = 1, bool dumpActivations = false, hipStream_t stream = 0) {
+        (void)dumpActivations;
+        bool result = true;
+        hipStream_t stream_compute, stream_copy;
+        if (!stream) {
+            gpuErrChk(hipStreamCreate(&stream_compute));
+        } else {
+            stream_compute = stream;
+        }
+        gpuErrChk(hipStreamCreate(&stream_copy));
+        const int num_chunks = (num_samples + num_samples_per_chunk - 1) / num_samples_per_chunk;
+        std::vector<hipEvent_t> event_compute(num_chunks), event_copy(num_chunks);
+        for (int j = 0; j < num_chunks; j++) {
+            gpuErrChk(hipEventCreateWithFlags(&event_compute[j], hipEventDisableTiming));
+            gpuErrChk(hipEventCreateWithFlags(&event_copy[j], hipEventDisableTiming));
+        }
+        for (int j = 0; j < num_chunks; j++) {
+            const int initSample = j * num_samples_per_chunk;
+            const int n = (j == num_chunks - 1) ? num_samples - initSample : num_samples_per_chunk;
+            m_num_samples_per_chunk = n;
+            result = result && run_partial(initSample, num_samples, batch_size, NULL, batch_size_per_block, true,
+                                           stream_compute);
+            gpuErrChk(hipEventRecord(event_compute[j], stream_compute));
+            gpuErrChk(hipStreamWaitEvent(stream_copy, event_compute[j], 0));
+            if (yOut != NULL) getYOut(yOut, initSample, n, stream_copy);
+            gpuErrChk(hipEventRecord(event_copy[j], stream_copy));
+        }
+        for (int j = 0; j < num_chunks; j++) {
+            const int initSample = j * num_samples_per_chunk;
+            const int n = (j == num_chunks - 1) ? num_samples - initSample : num_samples_per_chunk;
+            gpuErrChk(hipEventSynchronize(event_copy[j]));
+            consume(yOut, initSample, n);
+        }
+        m_num_samples_per_chunk = 0;
+        for (int j = 0; j < num_chunks; j++) {
+            gpuErrChk(hipEventDestroy(event_compute[j]));
+            gpuErrChk(hipEventDestroy(event_copy[j]));
+        }
+        if (stream != stream_compute) gpuErrChk(hipStreamDestroy(stream_compute));
+        gpuErrChk(hipStreamDestroy(stream_copy));
+        return result;
+    }
+
+    // Generates samples [init_sample, init_sample + chunk) continuing from device-resident state
+    // (history, dilation ring); chunk = the run_chunks chunk, or num_samples (nv_wavenet.cuh:499-635).
+    // Asynchronous on `stream`.  yOut (host or device, [maxBatch][maxSamples] ints) receives the
+    // whole sample buffer when non-NULL.
+    bool run_partial(int init_sample, int num_samples, int batch_size, int* yOut = NULL, int batch_size_per_block = 1,
+                     bool dumpActivations = false, hipStream_t stream = 0) {
+        assert(batch_size_per_block > 0 && batch_size_per_block < 5);
+        assert(batch_size % batch_size_per_block == 0);
+        assert(batch_size > 0 && batch_size <= m_maxBatch);
+        assert(num_samples <= m_maxSamples);
+        if (m_implementation == SINGLE_BLOCK) assert(S <= 4 * R);
+
+        wn::Params p;
+        p.wblob = m_wblob;
+        p.bias = m_bias;
+        p.embPrev = m_embedPrev;
+        p.embCur = m_embedCur;
+        p.cond = m_cond;
+        p.sel = m_outputSelectors;
+        p.ring = m_ring;
+        p.dil = m_dil;
+        p.ringOff = m_ringOff;
+        p.yInPrev = m_yInPrev;
+        p.yInCur = m_yInCur;
+        p.yOut = m_yOut;
+        p.xtOut = m_XtOut;
+        p.skipOut = m_skipOut;
+        p.zs = m_Zs;
+        p.za = m_Za;
+        p.p = m_p;
+        p.numLayers = m_numLayers;
+        p.batch = batch_size;
+        p.maxBatch = m_maxBatch;
+        p.numSamples = num_samples;
+        p.condSamples = m_maxSamples;
+        p.initSample = init_sample;
+        p.count = m_num_samples_per_chunk ? m_num_samples_per_chunk : num_samples;
+        if (p.initSample + p.count > num_samples) p.count = num_samples - p.initSample;
+        p.ringSlots = m_ringSlots;
+        p.groups = m_groups;
+        p.tanhEmbed = m_tanhEmbed ? 1 : 0;
+        p.dump = dumpActivations ? 1 : 0;
+        if (p.count <= 0) return true;
+
+        const size_t ldsBytes = ((size_t)m_numLayers * C::BIAS_L + 2 * A) * sizeof(float);
+        const int grid = (batch_size + 15) / 16;
+        hipLaunchKernelGGL((wn::wavenet_wave16<F16, R, S, A>), dim3(grid), dim3(64), ldsBytes, stream, p);
+        bool result = (hipGetLastError() == hipSuccess);
+        if (yOut != NULL) {
+            gpuErrChk(hipMemcpyAsync(yOut, m_yOut, (size_t)m_maxSamples * m_maxBatch * sizeof(int), hipMemcpyDefault,
+                                     stream));
+        }
+        return result;
+    }
+
+    bool run(int num_samples, int batch_size, int* yOut = NULL, int batch_size_per_block = 1,
+             bool dumpActivations = false, hipStream_t stream = 0) {
+        m_num_samples_per_chunk = 0;
+        return run_partial(0, num_samples, batch_size, yOut, batch_size_per_block, dumpActivations, stream);
+    }
+};

@@ -1,0 +1,159 @@
+// wavenet_capi.hip -- the C-ABI surface of libwavenet_infer.so:
+//   include/wavenet_infer.h  (the reference's pytorch/wavenet_infer.h, symbol for symbol)
+//   include/nv_wavenet_c.h   (handle API over every instantiation built into the library)
+#include <stdlib.h>
+
+#include <vector>
+
+#include "../../include/wavenet_infer.h"
+#include "engine_base.hpp"
+
+// ---- registry of instantiations (WN_INSTANCES comes from the Makefile) ----------------------
+#define X(R, S, A, P) nvw_engine* WN_FACTORY_NAME(R, S, A, P)(int, int, int, int, int, int);
+WN_INSTANCES
+#undef X
+
+namespace {
+struct Entry { int R, S, A, P; nvw_factory_fn make; };
+#define X(R, S, A, P) {R, S, A, P, WN_FACTORY_NAME(R, S, A, P)},
+const Entry kEntries[] = {WN_INSTANCES};
+#undef X
+const int kNumEntries = sizeof(kEntries) / sizeof(kEntries[0]);
+
+const Entry* findEntry(int R, int S, int A, int P) {
+    for (int i = 0; i < kNumEntries; i++)
+        if (kEntries[i].R == R && kEntries[i].S == S && kEntries[i].A == A && kEntries[i].P == P) return &kEntries[i];
+    return NULL;
+}
+}  // namespace
+
+extern "C" {
+
+int nvw_supported(int R, int S, int A, int precision) { return findEntry(R, S, A, precision) != NULL; }
+
+int nvw_list_supported(int* out, int max) {
+    for (int i = 0; i < kNumEntries && i < max; i++) {
+        out[4 * i] = kEntries[i].R; out[4 * i + 1] = kEntries[i].S;
+        out[4 * i + 2] = kEntries[i].A; out[4 * i + 3] = kEntries[i].P;
+    }
+    return kNumEntries;
+}
+
+nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int max_dilation, int batch_size,
+                       int num_samples, int implementation, int tanh_embed) {
+    const Entry* e = findEntry(R, S, A, precision);
+    if (!e) {
+        fprintf(stderr, "nvw_create: no nvWavenetInfer instantiation for R=%d S=%d A=%d fp%d in this build\n", R, S, A,
+                precision);
+        return NULL;
+    }
+    if (implementation < 0 || implementation > 4) {
+        fprintf(stderr, "nvw_create: implementation %d out of range 0..4\n", implementation);
+        return NULL;
+    }
+    return e->make(num_layers, max_dilation, batch_size, num_samples, implementation, tanh_embed);
+}
+void nvw_destroy(nvw_engine* e) { delete e; }
+
+void nvw_set_embeddings(nvw_engine* e, float* p, float* c) { e->setEmbeddings(p, c); }
+void nvw_set_layer_weights(nvw_engine* e, int layer, float* Wprev, float* Wcur, float* Bh, float* Wres, float* Bres,
+                           float* Wskip, float* Bskip) {
+    e->setLayerWeights(layer, Wprev, Wcur, Bh, Wres, Bres, Wskip, Bskip);
+}
+void nvw_set_out_weights(nvw_engine* e, float* Wzs, float* Bzs, float* Wza, float* Bza) {
+    e->setOutWeights(Wzs, Bzs, Wza, Bza);
+}
+void nvw_set_inputs(nvw_engine* e, float* Lh, float* sel) { e->setInputs(Lh, sel); }
+
+int nvw_run(nvw_engine* e, int num_samples, int batch_size, int* yOut, int bspb, int dump, void* stream) {
+    return e->run(num_samples, batch_size, yOut, bspb, dump != 0, (hipStream_t)stream) ? 1 : 0;
+}
+int nvw_run_partial(nvw_engine* e, int init_sample, int num_samples, int batch_size, int* yOut, int bspb, int dump,
+                    void* stream) {
+    return e->run_partial(init_sample, num_samples, batch_size, yOut, bspb, dump != 0, (hipStream_t)stream) ? 1 : 0;
+}
+int nvw_run_chunks(nvw_engine* e, int chunk, nvw_consume_fn consume, void* user, int num_samples, int batch_size,
+                   int* yOut, int bspb, int dump, void* stream) {
+    return e->run_chunks(chunk, consume, user, num_samples, batch_size, yOut, bspb, dump != 0, (hipStream_t)stream) ? 1
+                                                                                                                   : 0;
+}
+
+void nvw_get_xt_out(nvw_engine* e, int layer, float* d) { e->getXtOut(layer, d); }
+void nvw_get_skip_out(nvw_engine* e, int layer, float* d) { e->getSkipOut(layer, d); }
+void nvw_get_zs(nvw_engine* e, float* d) { e->getZs(d); }
+void nvw_get_za(nvw_engine* e, float* d) { e->getZa(d); }
+void nvw_get_p(nvw_engine* e, float* d) { e->getP(d); }
+void nvw_get_y_out(nvw_engine* e, int* yOut, int offset, int size, void* stream) {
+    e->getYOut(yOut, offset, size, (hipStream_t)stream);
+}
+
+void nvw_device_synchronize(void) { gpuErrChk(hipDeviceSynchronize()); }
+
+float nvw_time_runs(nvw_engine* e, int reps, int num_samples, int batch_size, int bspb, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t t0, t1;
+    gpuErrChk(hipEventCreate(&t0));
+    gpuErrChk(hipEventCreate(&t1));
+    gpuErrChk(hipEventRecord(t0, s));
+    for (int i = 0; i < reps; i++) e->run(num_samples, batch_size, NULL, bspb, false, s);
+    gpuErrChk(hipEventRecord(t1, s));
+    gpuErrChk(hipEventSynchronize(t1));
+    float ms = 0.f;
+    gpuErrChk(hipEventElapsedTime(&ms, t0, t1));
+    gpuErrChk(hipEventDestroy(t0));
+    gpuErrChk(hipEventDestroy(t1));
+    return ms;
+}
+
+// ---- the reference's PyTorch-path ABI (pytorch/wavenet_infer.cu:34-149) ----------------------
+#ifndef WAVENET_INFER_R
+#define WAVENET_INFER_R 64
+#define WAVENET_INFER_S 256
+#define WAVENET_INFER_A 256
+#endif
+
+int get_R(void) { return WAVENET_INFER_R; }
+int get_S(void) { return WAVENET_INFER_S; }
+int get_A(void) { return WAVENET_INFER_A; }
+
+void wavenet_infer(int sample_count, int batch_size, float* embedding_prev, float* embedding_curr, int num_layers,
+                   int max_dilation, float** in_layer_weights_prev, float** in_layer_weights_curr,
+                   float** in_layer_biases, float** res_layer_weights, float** res_layer_biases,
+                   float** skip_layer_weights, float** skip_layer_biases, float* conv_out_weight,
+                   float* conv_end_weight, int use_embed_tanh, float* cond_input, int implementation, int* samples) {
+    assert(samples);
+    // uniform draws in the reference's rand() order: Matrix(batch, samples).randomize(0.5, 1.0)
+    // iterates rows (utterances) outer, columns (samples) inner, two rand() per element, and
+    // stores column-major = [sample][batch] (wavenet_infer.cu:92-94, matrix.cpp:38-55).  Drawn
+    // before any HIP call: the HIP runtime itself consumes libc rand() while loading code
+    // objects, which would make the sequence depend on runtime internals.
+    std::vector<float> sel((size_t)sample_count * batch_size);
+    for (int b = 0; b < batch_size; b++) {
+        for (int s = 0; s < sample_count; s++) {
+            (void)rand();
+            float r = static_cast<float>(rand()) / static_cast<float>(RAND_MAX);
+            r -= 0.5;
+            r = r * 1.0f + 0.5f;
+            sel[(size_t)s * batch_size + b] = r;
+        }
+    }
+    nvw_engine* w = nvw_create(WAVENET_INFER_R, WAVENET_INFER_S, WAVENET_INFER_A, 32, num_layers, max_dilation,
+                               batch_size, sample_count, implementation, use_embed_tanh);
+    if (!w) exit(1);
+    w->setEmbeddings(embedding_prev, embedding_curr);
+    for (int l = 0; l < num_layers; l++)
+        w->setLayerWeights(l, in_layer_weights_prev[l], in_layer_weights_curr[l], in_layer_biases[l],
+                           res_layer_weights[l], res_layer_biases[l], skip_layer_weights[l], skip_layer_biases[l]);
+    // no biases on the two output layers (wavenet_infer.cu:75-82)
+    std::vector<float> zeroBias(WAVENET_INFER_A, 0.f);
+    w->setOutWeights(conv_out_weight, zeroBias.data(), conv_end_weight, zeroBias.data());
+    w->setInputs(cond_input, sel.data());
+    const int bspb = ((batch_size % 4) == 0) ? 4 : ((batch_size % 2) == 0) ? 2 : 1;
+    bool ok = w->run(sample_count, batch_size, samples, bspb, true, 0);
+    assert(ok);
+    (void)ok;
+    gpuErrChk(hipDeviceSynchronize());
+    delete w;
+}
+
+}  // extern "C"

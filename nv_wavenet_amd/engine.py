@@ -1,0 +1,155 @@
+"""WavenetEngine: the nvWavenetInfer<T_weight,T_data,R,S,A> class surface
+(/root/reference/nv_wavenet.cuh:220-640) reached through the C ABI (include/nv_wavenet_c.h).
+
+Method names, argument order, defaults and layouts are the reference's; arrays may be numpy
+(host) or torch (host or device) -- the engine copies them, like the reference does.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, addr, CONSUME_FN
+
+
+class Impl:
+    """nvWavenetInfer::Implementation (nv_wavenet.cuh:223-229). The reference's Python enum
+    (pytorch/nv_wavenet.py:53) stops at PERSISTENT; MANYBLOCK is exposed here as well."""
+    AUTO = 0
+    SINGLE_BLOCK = 1
+    DUAL_BLOCK = 2
+    PERSISTENT = 3
+    MANYBLOCK = 4
+
+
+def supported_configs():
+    buf = (C.c_int * 256)()
+    n = lib.nvw_list_supported(buf, 64)
+    return [tuple(buf[4 * i:4 * i + 4]) for i in range(min(n, 64))]
+
+
+def _f32(x):
+    if hasattr(x, "data_ptr"):
+        import torch
+        assert x.dtype == torch.float32, "expected float32"
+        return x
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return x
+
+
+class WavenetEngine:
+    def __init__(self, R, S, A, numLayers, maxDilation, batchSize, numSamples, impl=0, tanhEmbed=True,
+                 precision=32):
+        if not lib.nvw_supported(R, S, A, precision):
+            raise ValueError("no nvWavenetInfer<%s,R=%d,S=%d,A=%d> in this build; have %s" %
+                             ("half2,half" if precision == 16 else "float,float", R, S, A, supported_configs()))
+        if impl not in (0, 1, 2, 3, 4):
+            raise ValueError("implementation must be 0..4")
+        self.R, self.S, self.A = R, S, A
+        self.numLayers, self.maxDilation = numLayers, maxDilation
+        self.maxBatch, self.maxSamples = batchSize, numSamples
+        self.precision = precision
+        self._h = lib.nvw_create(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
+                                 1 if tanhEmbed else 0)
+        if not self._h:
+            raise RuntimeError("nvw_create failed")
+        self._cb_keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.nvw_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- model ------------------------------------------------------------------------------
+    def setEmbeddings(self, embedPrev, embedCur):
+        p, c = _f32(embedPrev), _f32(embedCur)
+        lib.nvw_set_embeddings(self._h, addr(p), addr(c))
+
+    def setLayerWeights(self, layer, Wprev, Wcur, Bh, Wres, Bres, Wskip, Bskip):
+        a = [_f32(x) for x in (Wprev, Wcur, Bh, Wres, Bres, Wskip, Bskip)]
+        lib.nvw_set_layer_weights(self._h, layer, *[addr(x) for x in a])
+
+    def setOutWeights(self, Wzs, Bzs, Wza, Bza):
+        a = [_f32(x) for x in (Wzs, Bzs, Wza, Bza)]
+        lib.nvw_set_out_weights(self._h, *[addr(x) for x in a])
+
+    def setInputs(self, Lh, outputSelectors):
+        """Lh [maxSamples][L][maxBatch][2R] fp32, outputSelectors [maxSamples][maxBatch] fp32."""
+        Lh, sel = _f32(Lh), _f32(outputSelectors)
+        n = self.maxSamples * self.numLayers * self.maxBatch * 2 * self.R
+        assert (Lh.numel() if hasattr(Lh, "numel") else Lh.size) == n, "Lh has the wrong size"
+        assert (sel.numel() if hasattr(sel, "numel") else sel.size) == self.maxSamples * self.maxBatch
+        lib.nvw_set_inputs(self._h, addr(Lh), addr(sel))
+
+    # ---- run --------------------------------------------------------------------------------
+    def _yout(self, yOut):
+        if yOut is None:
+            return None
+        if hasattr(yOut, "data_ptr"):
+            import torch
+            assert yOut.dtype == torch.int32
+        else:
+            assert yOut.dtype == np.int32 and yOut.flags["C_CONTIGUOUS"]
+        n = yOut.numel() if hasattr(yOut, "numel") else yOut.size
+        assert n >= self.maxBatch * self.maxSamples, "yOut must hold [maxBatch][maxSamples] int32"
+        return addr(yOut)
+
+    def run(self, num_samples, batch_size, yOut=None, batch_size_per_block=1, dumpActivations=False, stream=None):
+        ok = lib.nvw_run(self._h, num_samples, batch_size, self._yout(yOut), batch_size_per_block,
+                         1 if dumpActivations else 0, stream)
+        return bool(ok)
+
+    def run_partial(self, init_sample, num_samples, batch_size, yOut=None, batch_size_per_block=1,
+                    dumpActivations=False, stream=None):
+        ok = lib.nvw_run_partial(self._h, init_sample, num_samples, batch_size, self._yout(yOut),
+                                 batch_size_per_block, 1 if dumpActivations else 0, stream)
+        return bool(ok)
+
+    def run_chunks(self, num_samples_per_chunk, consume, num_samples, batch_size, yOut=None,
+                   batch_size_per_block=1, dumpActivations=False, stream=None):
+        """consume(yOut, init_sample, count) is called on this thread for every finished chunk."""
+        def _cb(_ptr, init, count, _user):
+            if consume is not None:
+                consume(yOut, init, count)
+        cb = CONSUME_FN(_cb)
+        self._cb_keep = cb
+        ok = lib.nvw_run_chunks(self._h, num_samples_per_chunk, cb, None, num_samples, batch_size,
+                                self._yout(yOut), batch_size_per_block, 1 if dumpActivations else 0, stream)
+        return bool(ok)
+
+    # ---- getters (host numpy, reference layouts) ----------------------------------------------
+    def _get(self, fn, shape, *pre):
+        out = np.zeros(shape, dtype=np.float32)
+        fn(self._h, *pre, addr(out))
+        return out
+
+    def getXtOut(self, layer):
+        return self._get(lib.nvw_get_xt_out, (self.maxBatch, self.R), layer)
+
+    def getSkipOut(self, layer):
+        return self._get(lib.nvw_get_skip_out, (self.maxBatch, self.S), layer)
+
+    def getZs(self):
+        return self._get(lib.nvw_get_zs, (self.maxBatch, self.A))
+
+    def getZa(self):
+        return self._get(lib.nvw_get_za, (self.maxBatch, self.A))
+
+    def getP(self):
+        return self._get(lib.nvw_get_p, (self.maxBatch, self.A))
+
+    def getYOut(self, yOut, offset, size, stream=None):
+        lib.nvw_get_y_out(self._h, self._yout(yOut), offset, size, stream)
+
+    def time_runs(self, reps, num_samples, batch_size, batch_size_per_block=1, stream=None):
+        """HIP-event milliseconds for `reps` back-to-back run() launches on `stream`."""
+        return float(lib.nvw_time_runs(self._h, reps, num_samples, batch_size, batch_size_per_block, stream))
+
+    @staticmethod
+    def synchronize():
+        lib.nvw_device_synchronize()

@@ -1,0 +1,89 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/*.h declares;
+host-side logic of the Python mirror of the reference wrapper. No compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    syms = set()
+    for h in ("wavenet_infer.h", "nv_wavenet_c.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        for m in re.finditer(r"^\s*(?:[A-Za-z_][\w\s\*]*?)\b(\w+)\s*\(", txt, flags=re.M):
+            name = m.group(1)
+            if name not in ("defined", "nvw_consume_fn") and not name.startswith("__"):
+                syms.add(name)
+    syms.discard("void")
+    return syms
+
+
+def test_library_exports_every_declared_symbol():
+    from nv_wavenet_amd import _lib
+    syms = _declared_symbols()
+    assert {"wavenet_infer", "get_R", "get_S", "get_A", "nvw_create", "nvw_run_chunks"} <= syms
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(syms) if not hasattr(lib, s)]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+    # and the Python binding table covers exactly the declared set
+    assert set(_lib.SIGNATURES) == syms
+
+
+def test_compiled_channel_counts_and_instantiations():
+    from nv_wavenet_amd import nv_wavenet_ext, supported_configs
+    assert (nv_wavenet_ext.num_res_channels(), nv_wavenet_ext.num_skip_channels(),
+            nv_wavenet_ext.num_out_channels()) == (64, 256, 256)  # pytorch/wavenet_infer.cu:35-37
+    cfg = set(supported_configs())
+    # the reference's tested channel combinations (README.md:5-10), fp32 and fp16
+    for rsa in ((32, 128, 256), (64, 128, 256), (64, 256, 256), (128, 256, 256)):
+        assert rsa + (32,) in cfg and rsa + (16,) in cfg
+
+
+def test_unsupported_config_is_rejected_loudly():
+    from nv_wavenet_amd import WavenetEngine
+    with pytest.raises(ValueError):
+        WavenetEngine(48, 128, 256, 4, 8, 1, 8)
+    with pytest.raises(ValueError):
+        WavenetEngine(64, 256, 256, 4, 8, 1, 8, impl=7)
+
+
+def test_column_major_matches_reference_semantics():
+    import torch
+    from nv_wavenet_amd.nv_wavenet import column_major
+    w = torch.arange(6, dtype=torch.float32).reshape(2, 3)       # M=2 rows, K=3
+    cm = column_major(w)                                          # -> [K][M] contiguous
+    assert cm.shape == (3, 2) and cm.is_contiguous()
+    assert cm.flatten().tolist() == [0, 3, 1, 4, 2, 5]            # W[m + k*M]
+    assert column_major(w.reshape(2, 3, 1)).equal(cm)
+    b = torch.arange(4.0)
+    assert column_major(b) is b
+    c = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)   # (2R,B,L,N)
+    cc = column_major(c)
+    assert cc.shape == (5, 4, 3, 2) and cc[1, 2, 0, 1] == c[1, 0, 2, 1]
+
+
+def test_nvwavenet_constructor_checks_shapes():
+    import torch
+    from nv_wavenet_amd.nv_wavenet import NVWaveNet
+    R, S, A, L = 64, 256, 256, 3
+    mk = lambda *s: torch.zeros(*s)
+    kw = dict(embedding_prev=mk(A, R), embedding_curr=mk(A, R), conv_out_weight=mk(A, S, 1),
+              conv_end_weight=mk(A, A, 1), dilate_weights=[mk(2 * R, R, 2) for _ in range(L)],
+              dilate_biases=[mk(2 * R) for _ in range(L)], max_dilation=4,
+              res_weights=[mk(R, R, 1) for _ in range(L - 1)], res_biases=[mk(R) for _ in range(L - 1)],
+              skip_weights=[mk(S, R, 1) for _ in range(L)], skip_biases=[mk(S) for _ in range(L)],
+              use_embed_tanh=False)
+    m = NVWaveNet(**kw)
+    assert m.num_layers == L and len(m.layers) == 7 * L
+    assert m.layers[0].shape == (R, 2 * R)        # Wprev of layer 0, column-major
+    bad = dict(kw, embedding_prev=mk(A, R + 1))
+    with pytest.raises(AssertionError):
+        NVWaveNet(**bad)
+    bad = dict(kw, dilate_weights=[mk(2 * R, R, 3) for _ in range(L)])
+    with pytest.raises(AssertionError):
+        NVWaveNet(**bad)

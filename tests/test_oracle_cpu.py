@@ -1,0 +1,77 @@
+"""CPU tests (no GPU): the oracle reproduces every committed fixture bit-for-bit.
+
+The fixtures in tests/golden/ were produced by the reference's own nv_wavenet_reference.cpp +
+matrix.cpp (tests/golden/make_golden.py); where the prebuilt oracle/_ref library is present the
+oracle is additionally pinned against it live.
+"""
+import numpy as np
+import pytest
+
+import cases
+import util
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize("case", cases.ALL_CASES, ids=lambda c: c.name)
+def test_oracle_matches_golden(case):
+    g = util.load_golden(case.name)
+    t = util.gen_inputs(case)
+    o = util.make_oracle(case, t)
+    s = case.shape
+    for it in range(case.iters):
+        y = o.run(s.N)
+        assert np.array_equal(y, g["yOut"][it]), "yOut differs from the fixture"
+        got = o.getters()
+        crc = [O.crc32(got[k]) for k in ("Xout", "skipOut", "Zs", "Za", "P")]
+        assert crc == [int(c) for c in g["crc_act"][it]], "activation CRCs differ from the fixture"
+    assert np.array_equal(got["Za"], g["Za"]) and np.array_equal(got["P"], g["P"])
+    o.close()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (reference build) not present")
+@pytest.mark.parametrize("case", [c for c in cases.REF_CASES if c.shape.R <= 64][:6], ids=lambda c: c.name)
+def test_oracle_matches_reference_build_live(case):
+    s = case.shape
+    t1 = O.gen_test_inputs(case.seed, case.prior, s, "oracle")
+    t2 = O.gen_test_inputs(case.seed, case.prior, s, "ref")
+    for a, b in zip(t1.arrays(), t2.arrays()):
+        assert np.array_equal(a, b)
+    o, r = util.make_oracle(case, t1), O.RefOracle(s.L, s.B, s.N, s.R, s.S, s.A, s.maxD)
+    r.set_model(t1)
+    r.set_inputs(t1.Lh, t1.sel)
+    for _ in range(case.iters):
+        assert np.array_equal(o.run(s.N), r.run(s.N))
+        go, gr = o.getters(), r.getters()
+        for k in go:
+            assert np.array_equal(go[k], gr[k]), k
+    o.close(), r.close()
+
+
+def test_oracle_chunked_equals_single_run_and_teacher_forcing():
+    """run(a)+run(b) from one setInputs is NOT run(a+b) in the reference (sample index restarts, so
+    the dilated history is logically cleared); teacher forcing with the oracle's own output
+    reproduces it exactly and reports CDF edges that bracket the draw."""
+    case = cases.BY_NAME["C1_R32S128A256_L8_B1"]
+    t = util.gen_inputs(case)
+    s = case.shape
+    o = util.make_oracle(case, t)
+    y, lo, hi = o.run(s.N, edges=True)
+    sel = t.sel.T  # [B][N]
+    assert np.all(lo <= sel) and np.all(sel < hi)
+    o2 = util.make_oracle(case, t)
+    y2 = o2.run(s.N, forced=y)
+    assert np.array_equal(y, y2)
+    o.close(), o2.close()
+
+
+def test_oracle_partial_batch():
+    """batch_size < maxBatch keeps the maxBatch stride of Lh / selectors (nv_wavenet.cuh:144)."""
+    case = cases.BY_NAME["R32S128A256_impl1"]
+    t = util.gen_inputs(case)
+    s = case.shape
+    o = util.make_oracle(case, t)
+    full = o.run(s.N)
+    o2 = util.make_oracle(case, t)
+    part = o2.run(s.N, batch_size=5)
+    assert np.array_equal(full[:5], part[:5])
+    o.close(), o2.close()
