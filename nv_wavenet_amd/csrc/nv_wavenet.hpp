@@ -8,9 +8,10 @@
 // violations assert, nv_wavenet_util.cuh:34-40).  Streams are hipStream_t.
 //
 // What is different underneath (see wn_kernels.hpp): all Implementation values run the
-// wave-per-16-utterances MFMA engine; batch_size_per_block is validated like the reference
-// (nv_wavenet.cuh:559-561) but the batch tile is fixed by the MFMA shape (16 utterances per
-// wavefront), so it is a no-op hint.  Device buffers are laid out for that engine, not for the
+// MFMA engine (one 4-wave workgroup per tile of 16 utterances, M split over the waves);
+// batch_size_per_block is validated like the reference (nv_wavenet.cuh:559-561) but the batch
+// tile is fixed by the MFMA shape (16 utterances, 1 or 2 tiles per workgroup chosen from the
+// batch size), so it is a no-op hint.  Device buffers are laid out for that engine, not for the
 // reference's kernels; the getters return the reference's layouts.
 #pragma once
 
@@ -47,11 +48,12 @@ public:
                   "T_weight/T_data must be <float,float> or <half2,half>");
 
 protected:
-    using C = wn::Cfg<F16, R, S, A>;
+    using C = wn::Cfg<F16, R, S, A, 1>;   // stream / layout constants do not depend on BT
+    static constexpr int MAXBT = 2;
     using elem = typename wn::Prec<F16>::elem;
 
     Implementation m_implementation;
-    int m_numLayers, m_maxBatch, m_maxSamples, m_maxDilation, m_groups;
+    int m_numLayers, m_maxBatch, m_maxSamples, m_maxDilation, m_tiles, m_numCUs;
     bool m_tanhEmbed;
     int m_num_samples_per_chunk;
     int m_ringSlots;
@@ -94,10 +96,13 @@ protected:
         size_t g = (n + 255) / 256;
         return (int)(g > 4096 ? 4096 : (g ? g : 1));
     }
-    void packWeight(elem* dst, const float* src, int M, int K, int rowperm) {
+    // col-major fp32 M x K -> the NW per-wave fragment streams; blockFrag = fragment offset of this
+    // matrix inside each wave's stream
+    void packWeight(size_t blockFrag, const float* src, int M, int K, int gateRT) {
         const float* d = onDevice(src, (size_t)M * K);
-        hipLaunchKernelGGL((wn::pack_weight_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0, dst, d, M, K,
-                           rowperm);
+        hipLaunchKernelGGL((wn::pack_weight_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0,
+                           m_wblob + blockFrag * C::FRAG_ELEMS, d, M, K, C::NW,
+                           C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS, gateRT);
         gpuErrChk(hipGetLastError());
         gpuErrChk(hipStreamSynchronize(0));
     }
@@ -107,8 +112,20 @@ protected:
         gpuErrChk(hipGetLastError());
         gpuErrChk(hipStreamSynchronize(0));
     }
-    elem* layerBlob(int layer) { return m_wblob + (size_t)layer * C::FL * 64 * C::EPL; }
-    elem* headBlob() { return layerBlob(m_numLayers); }
+    template <int BT> bool launch(const wn::Params& p, int tiles, hipStream_t stream) {
+        using CB = wn::Cfg<F16, R, S, A, BT>;
+        const int grid = (tiles + BT - 1) / BT;
+        hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT>), dim3(grid), dim3(CB::THREADS),
+                           CB::ldsBytes(m_numLayers), stream, p);
+        return hipGetLastError() == hipSuccess;
+    }
+    template <int BT> bool ldsFits() const { return wn::Cfg<F16, R, S, A, BT>::ldsBytes(m_numLayers) <= 160 * 1024; }
+    template <int BT> void allowLds() {
+        if (ldsFits<BT>())
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)wn::Cfg<F16, R, S, A, BT>::ldsBytes(m_numLayers)));
+    }
     float* headBias() { return m_bias + (size_t)m_numLayers * C::BIAS_L; }
 
 public:
@@ -118,7 +135,14 @@ public:
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
           m_num_samples_per_chunk(0), m_stage(NULL), m_stageElems(0) {
         assert(numLayers > 0 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
-        m_groups = (batchSize + 15) / 16;
+        m_tiles = ((batchSize + 15) / 16 + MAXBT - 1) / MAXBT * MAXBT;   // whole workgroups of MAXBT tiles
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            gpuErrChk(hipGetDevice(&dev));
+            gpuErrChk(hipGetDeviceProperties(&prop, dev));
+            m_numCUs = prop.multiProcessorCount;
+        }
 
         // dilation schedule (nv_wavenet.cuh:99,110-111): d doubles per layer, back to 1 past maxDilation
         std::vector<int> dil(numLayers), off(numLayers);
@@ -136,7 +160,7 @@ public:
         gpuErrChk(hipMemcpy(m_dil, dil.data(), numLayers * sizeof(int), hipMemcpyHostToDevice));
         gpuErrChk(hipMemcpy(m_ringOff, off.data(), numLayers * sizeof(int), hipMemcpyHostToDevice));
 
-        const size_t wElems = ((size_t)numLayers * C::FL + C::FH) * 64 * C::EPL;
+        const size_t wElems = (size_t)C::NW * C::waveStreamFrags(numLayers) * C::FRAG_ELEMS;
         gpuErrChk(hipMalloc(&m_wblob, wElems * sizeof(elem)));
         gpuErrChk(hipMemset(m_wblob, 0, wElems * sizeof(elem)));
         const size_t bElems = (size_t)numLayers * C::BIAS_L + 2 * A;
@@ -147,13 +171,13 @@ public:
         gpuErrChk(hipMemset(m_embedPrev, 0, (size_t)A * R * sizeof(elem)));
         gpuErrChk(hipMemset(m_embedCur, 0, (size_t)A * R * sizeof(elem)));
 
-        const size_t condElems = (size_t)numSamples * numLayers * m_groups * 16 * 2 * R;
+        const size_t condElems = (size_t)numSamples * numLayers * m_tiles * 16 * 2 * R;
         gpuErrChk(hipMalloc(&m_cond, condElems * sizeof(elem)));
         gpuErrChk(hipMemset(m_cond, 0, condElems * sizeof(elem)));
         gpuErrChk(hipMalloc(&m_outputSelectors, (size_t)numSamples * batchSize * sizeof(float)));
         gpuErrChk(hipMemset(m_outputSelectors, 0, (size_t)numSamples * batchSize * sizeof(float)));
 
-        const size_t ringElems = (size_t)m_groups * m_ringSlots * R * 16;
+        const size_t ringElems = (size_t)m_tiles * m_ringSlots * R * 16;
         gpuErrChk(hipMalloc(&m_ring, ringElems * sizeof(elem)));
         gpuErrChk(hipMemset(m_ring, 0, ringElems * sizeof(elem)));
 
@@ -176,9 +200,13 @@ public:
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
 
-        const size_t ldsBytes = bElems * sizeof(float);
-        gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wave16<F16, R, S, A>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        if (!ldsFits<1>()) {
+            fprintf(stderr, "nvWavenetInfer: R=%d S=%d A=%d with %d layers needs %zu bytes of LDS (> 160 KiB)\n", R, S,
+                    A, numLayers, wn::Cfg<F16, R, S, A, 1>::ldsBytes(numLayers));
+            exit(1);
+        }
+        allowLds<1>();
+        allowLds<2>();
         gpuErrChk(hipDeviceSynchronize());
     }
 
@@ -214,12 +242,11 @@ public:
     virtual void setLayerWeights(int layer, float* Wprev, float* Wcur, float* Bh, float* Wres, float* Bres,
                                  float* Wskip, float* Bskip) {
         assert(layer >= 0 && layer < m_numLayers);
-        elem* blob = layerBlob(layer);
-        const size_t fe = (size_t)64 * C::EPL;  // elements per fragment
-        packWeight(blob + C::O_PREV * fe, Wprev, 2 * R, R, 0);
-        packWeight(blob + C::O_CUR * fe, Wcur, 2 * R, R, 0);
-        packWeight(blob + C::O_RES * fe, Wres, R, R, 0);
-        packWeight(blob + C::O_SKIP * fe, Wskip, S, R, 0);
+        const size_t lf = (size_t)layer * C::FLW;
+        packWeight(lf + C::O_PREV, Wprev, 2 * R, R, C::RT);
+        packWeight(lf + C::O_CUR, Wcur, 2 * R, R, C::RT);
+        packWeight(lf + C::O_RES, Wres, R, R, 0);
+        packWeight(lf + C::O_SKIP, Wskip, S, R, 0);
         float* b = m_bias + (size_t)layer * C::BIAS_L;
         gpuErrChk(hipMemcpy(b, Bh, 2 * R * sizeof(float), hipMemcpyDefault));
         gpuErrChk(hipMemcpy(b + 2 * R, Bres, R * sizeof(float), hipMemcpyDefault));
@@ -227,10 +254,9 @@ public:
     }
     // col-major Wzs AxS, Bzs A, Wza AxA, Bza A (nv_wavenet.cuh:410-415)
     virtual void setOutWeights(float* Wzs, float* Bzs, float* Wza, float* Bza) {
-        elem* blob = headBlob();
-        const size_t fe = (size_t)64 * C::EPL;
-        packWeight(blob, Wzs, A, S, 0);
-        packWeight(blob + C::F_ZS * fe, Wza, A, A, 1);  // lane-contiguous logit rows
+        const size_t hf = (size_t)m_numLayers * C::FLW;
+        packWeight(hf, Wzs, A, S, 0);
+        packWeight(hf + C::FW_ZS, Wza, A, A, 0);
         gpuErrChk(hipMemcpy(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault));
         gpuErrChk(hipMemcpy(headBias() + A, Bza, A * sizeof(float), hipMemcpyDefault));
     }
@@ -242,7 +268,7 @@ public:
         gpuErrChk(hipGetLastError());
         const size_t rows = (size_t)m_maxSamples * m_numLayers;
         const size_t srcPerRow = (size_t)m_maxBatch * 2 * R;
-        const size_t dstPerRow = (size_t)m_groups * 16 * 2 * R;
+        const size_t dstPerRow = (size_t)m_tiles * 16 * 2 * R;
         const bool dev = isDevicePtr(Lh);
         // host sources go through the staging buffer in chunks of <= 64 Mi floats
         size_t chunkRows = dev ? rows : ((size_t)64 << 20) / srcPerRow;
@@ -251,7 +277,7 @@ public:
             const size_t nr = (rows - r0 < chunkRows) ? rows - r0 : chunkRows;
             const float* src = onDevice(Lh + r0 * srcPerRow, nr * srcPerRow);
             hipLaunchKernelGGL((wn::pack_cond_kernel<F16>), dim3(gridFor(nr * dstPerRow)), dim3(256), 0, 0,
-                               m_cond + r0 * dstPerRow, src, nr, m_maxBatch, m_groups, 2 * R);
+                               m_cond + r0 * dstPerRow, src, nr, m_maxBatch, m_tiles, R, C::NW);
             gpuErrChk(hipGetLastError());
             gpuErrChk(hipStreamSynchronize(0));
         }
@@ -367,15 +393,17 @@ public:
         p.count = m_num_samples_per_chunk ? m_num_samples_per_chunk : num_samples;
         if (p.initSample + p.count > num_samples) p.count = num_samples - p.initSample;
         p.ringSlots = m_ringSlots;
-        p.groups = m_groups;
+        p.tiles = m_tiles;
         p.tanhEmbed = m_tanhEmbed ? 1 : 0;
         p.dump = dumpActivations ? 1 : 0;
         if (p.count <= 0) return true;
 
-        const size_t ldsBytes = ((size_t)m_numLayers * C::BIAS_L + 2 * A) * sizeof(float);
-        const int grid = (batch_size + 15) / 16;
-        hipLaunchKernelGGL((wn::wavenet_wave16<F16, R, S, A>), dim3(grid), dim3(64), ldsBytes, stream, p);
-        bool result = (hipGetLastError() == hipSuccess);
+        // one tile of 16 utterances per workgroup while the CUs are not all busy (lowest latency);
+        // two tiles per workgroup share one pass over the weights beyond that
+        const int tiles = (batch_size + 15) / 16;
+        bool result;
+        if (tiles > m_numCUs && ldsFits<2>()) result = launch<2>(p, tiles, stream);
+        else result = launch<1>(p, tiles, stream);
         if (yOut != NULL) {
             gpuErrChk(hipMemcpyAsync(yOut, m_yOut, (size_t)m_maxSamples * m_maxBatch * sizeof(int), hipMemcpyDefault,
                                      stream));

@@ -3,33 +3,45 @@
 // Replaces the device side of the reference (all four kernel organisations of
 // /root/reference/nv_wavenet_singleblock.cuh, nv_wavenet_dualblock.cuh, nv_wavenet_persistent.cuh
 // and the shared per-layer functions nv_wavenet.cuh:87-207, matrix_math.cuh, softmax.cuh) with a
-// design that is native to CDNA4 rather than a translation of them:
+// design that is native to CDNA4 rather than a translation of them.
 //
-//   ONE WAVEFRONT = ONE BATCH TILE OF 16 UTTERANCES.
-//   Every mat-vec of the reference (one thread per output row, K weights in that thread's
-//   registers, nv_wavenet.cuh:131-157 / matrix_math.cuh:80-157) becomes a [M x K] x [K x 16] MFMA
-//   GEMM whose N dimension is the utterance index.  The MFMA result tile (lane (g,j) holds rows
-//   4g..4g+3 of utterance j) is, after a K re-ordering that is folded into the host-side weight
-//   packing, exactly the B-operand fragment of the next MFMA, so activations flow
-//   embedding -> L layers -> head -> softmax entirely in registers of one wave: no LDS round
-//   trips, no barriers, no named-barrier role choreography, no inter-block flags.
-//   Weights are stored pre-swizzled in MFMA A-fragment order (1 KiB per fragment, 16 B per lane)
-//   and streamed from L2 straight into VGPRs through a software prefetch ring, a whole-sample
-//   loop: [layer 0 .. layer L-1][head] and around again.
+//   * The batch is the MFMA N dimension.  Every mat-vec of the reference (one thread per output
+//     row, K weights in that thread's registers, nv_wavenet.cuh:131-157, matrix_math.cuh:80-157)
+//     becomes a [M x K] x [K x 16] MFMA GEMM over a tile of 16 utterances (BT tiles per
+//     workgroup share one pass over the weights).
+//   * One workgroup = NW (4) wavefronts, one per SIMD, all working on the SAME utterance tile:
+//     the M (output-row) dimension of every GEMM is split across the waves, so each wave streams
+//     only its quarter of the weights.  Measured on MI355X (scripts/ubench/stream.hip): one wave
+//     sustains ~30 GB/s of L2->VGPR traffic whatever the prefetch depth (the VGPR return path
+//     of a SIMD), four waves on four SIMDs sustain 4x that -- so the weight stream, which is the
+//     bound of this path, has to be spread over all SIMDs of the CU.
+//   * Weights are pre-swizzled on upload into MFMA A-fragment order, per wave, in consumption
+//     order: each wave reads ONE contiguous stream [layer 0 .. layer L-1][head] with 1-KiB
+//     coalesced global_load_dwordx4, PF fragments ahead, straight into VGPRs (no LDS staging:
+//     a fragment is used by exactly one wave).
+//   * The MFMA result tile (lane (g,j): rows 4g..4g+3 of utterance j), converted to T_data, IS
+//     the B-operand fragment of the next MFMA once the K order is permuted accordingly (done in
+//     the weight packing), so activations are exchanged between the waves as ready-made
+//     B fragments through LDS: one ds_write_b64 per produced tile, ds_read_b128 per consumed
+//     fragment, conflict-free, one s_barrier per exchange (raw s_barrier + lgkmcnt only, so the
+//     in-flight weight prefetch is never drained).
+//   * Biases live in LDS for the whole launch and initialise the MFMA accumulators.
+//   * The dilated history x_l[t-d_l] is a ring of exactly d_l slots per layer in global memory
+//     (B-fragment order, 1-KiB coalesced rows, prefetched one layer ahead): sum(d_l)*R*16
+//     elements per tile instead of the reference's (maxDilation+1)*(L+1) planes
+//     (nv_wavenet.cuh:334-335).
+//   * softmax + inverse-CDF pick: logits go through LDS once; 16 lanes per utterance, reductions
+//     with cross-lane shuffles inside a 16-lane row.
 //
-// Data layouts private to the engine (produced by the pack kernels below):
-//   weight fragment f of an M x K matrix (tiles of 16 rows, k-frags of 16*TPF columns):
-//       frag (mt,kf), lane l=(g<<4|i), element e  <-  W[m][k],
-//       m = mt*16 + i                       (natural rows)
-//         | (i>>2)*(M/4) + mt*4 + (i&3)     (ROWPERM: lane-contiguous rows, used for the logits)
-//       k = (kf*TPF + (e>>2))*16 + g*4 + (e&3)
-//   activation tile t of a vector v (D layout): lane (g,j) reg r = v[t*16 + g*4 + r] of utt j
-//   conditioning: [sample][layer][group][chunk][lane][EPL]  (same (tile,g,r) mapping)
-//   dilation ring: per group, per layer l exactly d_l slots of R x 16 elements in B-frag order
+// Layouts private to the engine (produced by the pack kernels at the bottom):
+//   fragment of an M x K weight matrix: 16 rows x (16*TPF) k-values, 64 lanes x 16 B:
+//       lane l=(g<<4|i), element e  <-  W[tile*16 + i][ (kf*TPF + (e>>2))*16 + g*4 + (e&3) ]
+//   activation tile t of a vector v (MFMA D layout): lane (g,j) reg r = v[t*16 + g*4 + r] of utt j
+//   wave w owns tiles t = w, w+NW, w+2NW, ... of every GEMM output.
 //
-// fp32 (T_data=float) uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains); fp16 (T_data=half)
-// uses v_mfma_f32_16x16x32_f16 with fp32 accumulation (the reference accumulates in fp16,
-// matrix_math.cuh:119-157) and fp32 transcendentals / softmax like the reference
+// fp32 (T_data=float): v_mfma_f32_16x16x4_f32, exact fp32 FMA chains.  fp16 (T_data=half):
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation (the reference accumulates in fp16,
+// matrix_math.cuh:119-157), fp32 transcendentals / softmax like the reference
 // (nv_wavenet_util.cuh:78-86, softmax.cuh:43-47).
 #pragma once
 
@@ -66,40 +78,57 @@ constexpr int pick_pf(int fl, int pfmax) {
         if (fl % d == 0) best = d;
     return best;
 }
+constexpr int align16(int x) { return (x + 15) & ~15; }
 
-template <bool F16, int R, int S, int A>
+template <bool F16, int R, int S, int A, int BT>
 struct Cfg {
     using P = Prec<F16>;
-    static_assert(R % (16 * P::TPF) == 0 && S % (16 * P::TPF) == 0 && A % (16 * P::TPF) == 0,
-                  "R,S,A must be multiples of the MFMA K step");
-    static_assert(A % 64 == 0, "A must be a multiple of 64");
     static constexpr int TPF = P::TPF, EPL = P::EPL;
-    static constexpr int RT = R / 16, R2T = 2 * R / 16, ST = S / 16, AT = A / 16;
+    static constexpr int RT = R / 16, ST = S / 16, AT = A / 16;
+    static constexpr int NW = RT >= 4 ? 4 : RT;            // wavefronts per workgroup
+    static_assert(R % (16 * TPF) == 0 && S % (16 * TPF) == 0 && A % (16 * TPF) == 0, "R,S,A vs MFMA K step");
+    static_assert(RT % NW == 0 && ST % NW == 0 && AT % NW == 0, "tiles must split evenly over the waves");
+    static constexpr int THREADS = NW * 64;
+    static constexpr int HTW = RT / NW, STW = ST / NW, ATW = AT / NW;   // tiles per wave
     static constexpr int KF_R = RT / TPF, KF_S = ST / TPF, KF_A = AT / TPF;
-    static constexpr int F_PREV = R2T * KF_R, F_CUR = R2T * KF_R, F_RES = RT * KF_R, F_SKIP = ST * KF_R;
-    static constexpr int O_PREV = 0, O_CUR = F_PREV, O_RES = O_CUR + F_CUR, O_SKIP = O_RES + F_RES;
-    static constexpr int FL = O_SKIP + F_SKIP;             // fragments per layer
-    static constexpr int F_ZS = AT * KF_S, F_ZA = AT * KF_A;
-    static constexpr int FH = F_ZS + F_ZA;                 // fragments of the output head
-    // depth of the weight prefetch ring (4 VGPRs per fragment in flight)
-    static constexpr int PFMAX = F16 ? (R <= 64 ? 40 : 36) : (R <= 64 ? 36 : 28);
-    static constexpr int PF = pick_pf(FL, PFMAX);
-    static_assert(FL % PF == 0 && PF <= FH, "prefetch ring must divide the layer stream");
+    // per-wave fragment stream of one layer: prev | cur | res | skip
+    static constexpr int FW_GATE = 2 * HTW * KF_R, FW_RES = HTW * KF_R, FW_SKIP = STW * KF_R;
+    static constexpr int O_PREV = 0, O_CUR = FW_GATE, O_RES = 2 * FW_GATE, O_SKIP = O_RES + FW_RES;
+    static constexpr int FLW = O_SKIP + FW_SKIP;
+    // per-wave fragment stream of the head: zs | za
+    static constexpr int FW_ZS = ATW * KF_S, FW_ZA = ATW * KF_A;
+    static constexpr int FHW = FW_ZS + FW_ZA;
+    static constexpr int PF = pick_pf(FLW, 24);
+    static_assert(FLW % PF == 0 && PF <= FHW, "prefetch ring must divide the layer stream");
+    static constexpr int FRAG_ELEMS = 64 * EPL;
     static constexpr int BIAS_L = 3 * R + S;               // fp32 biases per layer: Bh | Bres | Bskip
-    static constexpr int COND_CH = R2T / TPF;              // conditioning fragments per (sample,layer,group)
-    static constexpr int RING_FR = KF_R;                   // fragments per ring slot
-    static constexpr int ZA_REGS = A / 4;                  // logits per lane
+    static constexpr int COND_FR = 2 * HTW / TPF;          // conditioning fragments per (sample,layer,tile,wave)
+    static constexpr int LPU = 4 * NW;                     // softmax lanes per utterance
+    static constexpr int RPL = A / LPU;                    // logits per softmax lane
+    static_assert(RPL % 4 == 0, "A too small for the softmax lane split");
+    // ---- LDS layout (bytes); the fp32 bias table (runtime size) follows at LDS_FIXED ----
+    static constexpr int XBUF = BT * KF_R * 1024;          // x as B fragments
+    static constexpr int HBUF = XBUF;
+    static constexpr int SKBUF = BT * KF_S * 1024;
+    static constexpr int ZSBUF = BT * KF_A * 1024;
+    static constexpr int LROW = A + 4;                     // padded logits row (floats)
+    static constexpr int LGBUF = BT * 16 * LROW * 4;
+    static constexpr int YBUF = align16(BT * 16 * 4);
+    static constexpr int OFF_X = 0, OFF_H = OFF_X + XBUF, OFF_SK = OFF_H + HBUF, OFF_ZS = OFF_SK + SKBUF;
+    static constexpr int OFF_LG = OFF_ZS + ZSBUF, OFF_Y = OFF_LG + LGBUF, LDS_FIXED = OFF_Y + YBUF;
+    static size_t ldsBytes(int L) { return (size_t)LDS_FIXED + ((size_t)L * BIAS_L + 2 * A) * sizeof(float); }
+    __host__ __device__ static size_t waveStreamFrags(int L) { return (size_t)L * FLW + FHW; }
 };
 
 // Everything the kernel needs, passed by value (role of nv_wavenet_params, nv_wavenet.cuh:40-85).
 struct Params {
-    const void* wblob;       // [L][FL] layer fragments, then [FH] head fragments (1 KiB each)
-    const float* bias;       // [L][BIAS_L] then Bzs[A], Bza[A] (Bza natural order)
+    const void* wblob;       // NW per-wave streams: [L][FLW] layer fragments then [FHW] head fragments
+    const float* bias;       // [L][BIAS_L] then Bzs[A], Bza[A]
     const void* embPrev;     // [A][R] T_data
     const void* embCur;      // [A][R] T_data
-    const void* cond;        // packed conditioning, see header
+    const void* cond;        // [sample][L][tile][wave][COND_FR] fragments
     const float* sel;        // [N][maxBatch] uniform draws
-    void* ring;              // [groups][ringSlots][RING_FR] fragments
+    void* ring;              // [tile][ringSlots][KF_R] fragments
     const int* dil;          // [L] dilation of layer l
     const int* ringOff;      // [L] first ring slot of layer l
     int* yInPrev;            // [maxBatch]
@@ -112,13 +141,13 @@ struct Params {
     float* p;                // [maxBatch][A]      (dump)
     int numLayers;
     int batch;               // utterances to generate (<= maxBatch)
-    int maxBatch;            // batch stride of cond / sel / dumps
-    int numSamples;          // row stride of yOut and bound of the conditioning
+    int maxBatch;            // batch stride of sel / dumps
+    int numSamples;          // row stride of yOut
     int condSamples;         // samples held in cond / sel (maxSamples)
     int initSample;
     int count;               // samples generated by this launch
     int ringSlots;           // sum of dilations
-    int groups;              // ceil(maxBatch/16): group stride of cond
+    int tiles;               // ceil(maxBatch/16): tile stride of cond / ring
     int tanhEmbed;
     int dump;
 };
@@ -139,17 +168,16 @@ WN_DEV float tanh_fast(float x) {
     return 1.0f - 2.0f * fast_rcp(e + 1.0f);
 }
 // tanh, fp32 engine: the formula above loses relative accuracy for small |x| (cancellation), and
-// the parity bars are relative (nv_wavenet_test.cu:273-298), so use an odd minimax-style series
-// below 0.55 and the exponential form above it.
+// the parity bars are relative (nv_wavenet_test.cu:273-298), so use the odd Taylor series below
+// 0.55 and the exponential form above it.
 WN_DEV float tanh_acc(float x) {
     float a = __builtin_fabsf(x);
     float x2 = x * x;
-    // x*(1 + x2*(-1/3 + x2*(2/15 + x2*(-17/315 + x2*(62/2835 + x2*(-1382/155925))))))
-    float pz = -0.00886323552990220f;
-    pz = __builtin_fmaf(pz, x2, 0.0218694885361552f);
-    pz = __builtin_fmaf(pz, x2, -0.0539682539682540f);
-    pz = __builtin_fmaf(pz, x2, 0.133333333333333f);
-    pz = __builtin_fmaf(pz, x2, -0.333333333333333f);
+    float pz = -0.00886323552990220f;                       // -1382/155925
+    pz = __builtin_fmaf(pz, x2, 0.0218694885361552f);       //  62/2835
+    pz = __builtin_fmaf(pz, x2, -0.0539682539682540f);      // -17/315
+    pz = __builtin_fmaf(pz, x2, 0.133333333333333f);        //  2/15
+    pz = __builtin_fmaf(pz, x2, -0.333333333333333f);       // -1/3
     float small = __builtin_fmaf(x * x2, pz, x);
     float e = fast_exp(2.0f * a);
     float big = 1.0f - 2.0f * fast_rcp(e + 1.0f);
@@ -167,35 +195,28 @@ WN_DEV floatx4 mma(floatx4 a, floatx4 b, floatx4 c) {
     return c;
 }
 
-// D tiles (fp32) -> B-operand fragments
-template <int KT> WN_DEV void to_bfrags(const floatx4 (&t)[KT], half8 (&b)[KT / 2]) {
-#pragma unroll
-    for (int k = 0; k < KT / 2; k++) {
-        half8 r;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            r[e] = (_Float16)t[2 * k][e];
-            r[4 + e] = (_Float16)t[2 * k + 1][e];
-        }
-        b[k] = r;
-    }
-}
-template <int KT> WN_DEV void to_bfrags(const floatx4 (&t)[KT], floatx4 (&b)[KT]) {
-#pragma unroll
-    for (int k = 0; k < KT; k++) b[k] = t[k];
-}
-
 WN_DEV floatx4 quad_to_f32(half4 q) { return floatx4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]}; }
 WN_DEV floatx4 quad_to_f32(floatx4 q) { return q; }
 
-// fragment element e of a conditioning / activation fragment -> (tile-in-frag, reg)
-template <bool F16, int NF>
-WN_DEV void add_frags(floatx4* acc, const typename Prec<F16>::frag (&c)[NF]) {
-    constexpr int TPF = Prec<F16>::TPF;
+// Workgroup barrier that does NOT wait for outstanding global loads (the weight prefetch ring
+// stays in flight across it): only this wave's LDS traffic is drained. __syncthreads() would emit
+// s_waitcnt vmcnt(0) as well.
+WN_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- LDS exchange of activations as B fragments -------------------------------------------
+// tile t of a vector, held in MFMA D layout (fp32), goes to its place in the fragment image
+template <bool F16> WN_DEV void lds_put_tile(char* buf, int tile, int lane, floatx4 v);
+template <> WN_DEV void lds_put_tile<true>(char* buf, int tile, int lane, floatx4 v) {
+    half4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    *(half4*)(buf + (((tile >> 1) * 64 + lane) << 4) + ((tile & 1) << 3)) = h;
+}
+template <> WN_DEV void lds_put_tile<false>(char* buf, int tile, int lane, floatx4 v) {
+    *(floatx4*)(buf + ((tile * 64 + lane) << 4)) = v;
+}
+template <bool F16, int KF>
+WN_DEV void lds_get_frags(const char* buf, int lane, typename Prec<F16>::frag (&b)[KF]) {
 #pragma unroll
-    for (int f = 0; f < NF; f++)
-#pragma unroll
-        for (int e = 0; e < Prec<F16>::EPL; e++) acc[f * TPF + (e >> 2)][e & 3] += (float)c[f][e];
+    for (int k = 0; k < KF; k++) b[k] = *(const typename Prec<F16>::frag*)(buf + ((k * 64 + lane) << 4));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -205,9 +226,9 @@ template <bool F16, int PF> struct WStream {
     typename Prec<F16>::frag buf[PF];
 };
 
-// Consume fragment `idx` (position inside the current body, compile-time after unrolling) and
-// refill its ring slot with fragment idx+PF: from the current body while that is inside it
-// (BODY fragments long), otherwise from `next` (the body that follows in the stream).
+// Consume fragment `idx` (position inside the current body, a compile-time constant after
+// unrolling) and refill its ring slot with fragment idx+PF: from the current body while that is
+// inside it (BODY fragments long), otherwise from `next` (the body that follows in the stream).
 template <bool F16, int PF, int BODY>
 WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const typename Prec<F16>::frag* cur,
                                      const typename Prec<F16>::frag* next) {
@@ -218,306 +239,416 @@ WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const typena
     return a;
 }
 
-template <bool F16, int PF, int BODY, int MT, int KF>
+// acc[bt][mt] += W(tile mt) * b[bt]   for MT tiles of this wave, KF k-fragments, BT batch tiles
+template <bool F16, int PF, int BODY, int BT, int MT, int KF>
 WN_DEV void gemm(WStream<F16, PF>& ws, int pos0, const typename Prec<F16>::frag* cur,
-                 const typename Prec<F16>::frag* next, floatx4 (&acc)[MT],
-                 const typename Prec<F16>::frag (&b)[KF]) {
+                 const typename Prec<F16>::frag* next, floatx4 (&acc)[BT][MT],
+                 const typename Prec<F16>::frag (&b)[BT][KF]) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
         for (int kf = 0; kf < KF; kf++) {
             auto a = take<F16, PF, BODY>(ws, pos0 + mt * KF + kf, cur, next);
-            acc[mt] = mma(a, b[kf], acc[mt]);
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) acc[bt][mt] = mma(a, b[bt][kf], acc[bt][mt]);
         }
-        // keep the scheduler from hoisting the whole body's refills above their ring slots'
-        // consumers (in SSA they are independent values): that only creates spills.
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// the engine kernel
+// the engine kernel: one workgroup generates `count` samples for BT tiles of 16 utterances
 // ------------------------------------------------------------------------------------------
-template <bool F16, int R, int S, int A>
-__global__ __launch_bounds__(64, 1) void wavenet_wave16(const Params p) {
-    using C = Cfg<F16, R, S, A>;
+template <bool F16, int R, int S, int A, int BT>
+__global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_wg(const Params p) {
+    using C = Cfg<F16, R, S, A, BT>;
     using P = Prec<F16>;
     using frag = typename P::frag;
     using quad = typename P::quad;
     using elem = typename P::elem;
-    constexpr int PF = C::PF, FL = C::FL, FH = C::FH;
-    constexpr int RT = C::RT, R2T = C::R2T, ST = C::ST, AT = C::AT;
+    constexpr int PF = C::PF, FLW = C::FLW, FHW = C::FHW, NW = C::NW;
+    constexpr int RT = C::RT, HTW = C::HTW, STW = C::STW, ATW = C::ATW;
+    constexpr int KF_R = C::KF_R, KF_S = C::KF_S, KF_A = C::KF_A;
 
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const xbuf = lds + C::OFF_X;
+    char* const hbuf = lds + C::OFF_H;
+    char* const skbuf = lds + C::OFF_SK;
+    char* const zsbuf = lds + C::OFF_ZS;
+    float* const lgbuf = (float*)(lds + C::OFF_LG);
+    int* const ybuf = (int*)(lds + C::OFF_Y);
+    float* const biasLds = (float*)(lds + C::LDS_FIXED);
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int grp = blockIdx.x;
-    const int b = grp * 16 + j;
-    const bool valid = b < p.batch;
-    const int bc = valid ? b : p.batch - 1;
     const int L = p.numLayers;
+    const int tile0 = blockIdx.x * BT;
 
-    // ---- biases -> LDS (read as accumulator initial values, broadcast per g) -------------
+    // utterance of this lane in its MFMA role (column j of tile bt)
+    int ub[BT];
+    bool uvalid[BT];
+#pragma unroll
+    for (int bt = 0; bt < BT; bt++) {
+        const int b = (tile0 + bt) * 16 + j;
+        uvalid[bt] = b < p.batch;
+        ub[bt] = uvalid[bt] ? b : p.batch - 1;
+    }
+    // utterance of this lane in its softmax role: 16 utterances over NW*64 lanes
+    const int su = tid / C::LPU, sq = tid % C::LPU;
+
+    // ---- biases -> LDS ----------------------------------------------------------------------
     {
         const int nb = L * C::BIAS_L + 2 * A;
-        for (int i = lane; i < nb; i += 64) lds[i] = p.bias[i];
-        __syncthreads();
+        for (int i = tid; i < nb; i += C::THREADS) biasLds[i] = p.bias[i];
     }
-    const float* ldsHead = lds + L * C::BIAS_L;
+    const float* const headBias = biasLds + L * C::BIAS_L;
 
-    const frag* wbase = (const frag*)p.wblob + lane;
-    const frag* whead = wbase + (size_t)L * FL * 64;
-    const elem* embPrev = (const elem*)p.embPrev;
-    const elem* embCur = (const elem*)p.embCur;
-    const frag* condBase = (const frag*)p.cond + lane;
-    frag* ringBase = (frag*)p.ring + (size_t)grp * p.ringSlots * C::RING_FR * 64 + lane;
+    const frag* const wbase = (const frag*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 64 + lane;
+    const frag* const whead = wbase + (size_t)L * FLW * 64;
+    const elem* const embPrev = (const elem*)p.embPrev;
+    const elem* const embCur = (const elem*)p.embCur;
+    const frag* const condBase = (const frag*)p.cond + lane;
+    frag* const ringBase = (frag*)p.ring + lane;
 
-    int yPrev = p.yInPrev[bc];
-    int yCur = p.yInCur[bc];
-
-    // embedding row of the older tap is known one sample early
-    floatx4 ep[RT];
+    int yPrev[BT], yCur[BT];
+    floatx4 ep[BT][HTW];      // embedding row of the older tap, known one sample early
 #pragma unroll
-    for (int t = 0; t < RT; t++) ep[t] = quad_to_f32(*(const quad*)(embPrev + (size_t)yPrev * R + t * 16 + g * 4));
+    for (int bt = 0; bt < BT; bt++) {
+        yPrev[bt] = p.yInPrev[ub[bt]];
+        yCur[bt] = p.yInCur[ub[bt]];
+#pragma unroll
+        for (int i = 0; i < HTW; i++)
+            ep[bt][i] = quad_to_f32(*(const quad*)(embPrev + (size_t)yPrev[bt] * R + (w + NW * i) * 16 + g * 4));
+    }
 
-    // ---- prime the weight ring ------------------------------------------------------------
+    // ---- prime the weight ring ----------------------------------------------------------------
     WStream<F16, PF> ws;
 #pragma unroll
     for (int i = 0; i < PF; i++) ws.buf[i] = wbase[(size_t)i * 64];
 
-    // ---- prefetch layer 0 of the first sample: dilated input + conditioning ---------------
-    frag xpN[C::RING_FR];
-    frag cdN[C::COND_CH];
-    {
-        const int t0 = p.initSample;
-        const int d0 = p.dil[0];
-        const frag* rp = ringBase + (size_t)(p.ringOff[0] + (t0 & (d0 - 1))) * C::RING_FR * 64;
+    // ---- prefetch of the dilated input + conditioning of (sample tn, layer ln) ----------------
+    frag xpN[BT][KF_R];
+    frag cdN[BT][C::COND_FR];
+    auto prefetch = [&](int tn, int ln) {
+        const int dn = p.dil[ln];
+        const int tc = tn < p.condSamples ? tn : p.condSamples - 1;
 #pragma unroll
-        for (int k = 0; k < C::RING_FR; k++) xpN[k] = rp[k * 64];
-        const frag* cp = condBase + ((size_t)t0 * L * p.groups + grp) * C::COND_CH * 64;
+        for (int bt = 0; bt < BT; bt++) {
+            const frag* rp =
+                ringBase + ((size_t)(tile0 + bt) * p.ringSlots + p.ringOff[ln] + (tn & (dn - 1))) * KF_R * 64;
 #pragma unroll
-        for (int k = 0; k < C::COND_CH; k++) cdN[k] = cp[k * 64];
-    }
+            for (int k = 0; k < KF_R; k++) xpN[bt][k] = rp[k * 64];
+            const frag* cp = condBase + ((((size_t)tc * L + ln) * p.tiles + tile0 + bt) * NW + w) * C::COND_FR * 64;
+#pragma unroll
+            for (int k = 0; k < C::COND_FR; k++) cdN[bt][k] = cp[k * 64];
+        }
+    };
+    prefetch(p.initSample, 0);
+
+    __syncthreads();   // bias table visible
 
     const int tEnd = p.initSample + p.count;
     for (int t = p.initSample; t < tEnd; t++) {
         const bool dumpNow = p.dump && (t == tEnd - 1);
 
-        // ---- embedding (nv_wavenet_reference.cpp:42-56) ----------------------------------
-        floatx4 x[RT];
+        // selector of the utterance this lane serves in the softmax
+        float selv[BT];
 #pragma unroll
-        for (int tt = 0; tt < RT; tt++) {
-            floatx4 ec = quad_to_f32(*(const quad*)(embCur + (size_t)yCur * R + tt * 16 + g * 4));
-            floatx4 v = ep[tt] + ec;
-            if (p.tanhEmbed) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = tanh_t<F16>(v[r]);
-            }
-            x[tt] = v;
+        for (int bt = 0; bt < BT; bt++) {
+            int sb = (tile0 + bt) * 16 + su;
+            sb = sb < p.batch ? sb : p.batch - 1;
+            selv[bt] = p.sel[(size_t)t * p.maxBatch + sb];
         }
-#pragma unroll
-        for (int tt = 0; tt < RT; tt++)
-            ep[tt] = quad_to_f32(*(const quad*)(embPrev + (size_t)yCur * R + tt * 16 + g * 4));
-        const float selv = p.sel[(size_t)t * p.maxBatch + bc];
 
-        floatx4 skip[ST];
+        // ---- embedding (nv_wavenet_reference.cpp:42-56): each wave makes its own x tiles ------
+        floatx4 x[BT][HTW];
 #pragma unroll
-        for (int i = 0; i < ST; i++) skip[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-        // ---- L dilated layers (nv_wavenet_reference.cpp:58-92) ---------------------------
-        for (int l = 0; l < L; l++) {
-            const frag* wl = wbase + (size_t)l * FL * 64;
-            const frag* wn = wl + (size_t)FL * 64;  // next layer, or the head after the last
-            const float* bl = lds + l * C::BIAS_L;
-            const int d = p.dil[l];
-
-            frag xb[C::KF_R];
-            to_bfrags<RT>(x, xb);
-
-            // dilated input x_l[t-d] was prefetched; zero before the start (reference :287)
-            frag xp[C::RING_FR];
-            frag cd[C::COND_CH];
-            const bool havePrev = t >= d;
+        for (int bt = 0; bt < BT; bt++) {
 #pragma unroll
-            for (int k = 0; k < C::RING_FR; k++) {
-                xp[k] = xpN[k];
-                if (!havePrev) {
+            for (int i = 0; i < HTW; i++) {
+                const int tile = w + NW * i;
+                floatx4 ec = quad_to_f32(*(const quad*)(embCur + (size_t)yCur[bt] * R + tile * 16 + g * 4));
+                floatx4 v = ep[bt][i] + ec;
+                if (p.tanhEmbed) {
 #pragma unroll
-                    for (int e = 0; e < P::EPL; e++) xp[k][e] = (elem)0.f;
+                    for (int r = 0; r < 4; r++) v[r] = tanh_t<F16>(v[r]);
                 }
+                x[bt][i] = v;
+                lds_put_tile<F16>(xbuf + bt * KF_R * 1024, tile, lane, v);
             }
 #pragma unroll
-            for (int k = 0; k < C::COND_CH; k++) cd[k] = cdN[k];
-            // x_l[t] replaces x_l[t-d] in the ring (same slot)
-            {
-                frag* rp = ringBase + (size_t)(p.ringOff[l] + (t & (d - 1))) * C::RING_FR * 64;
+            for (int i = 0; i < HTW; i++)
+                ep[bt][i] = quad_to_f32(*(const quad*)(embPrev + (size_t)yCur[bt] * R + (w + NW * i) * 16 + g * 4));
+        }
+        wg_barrier();
+
+        floatx4 skip[BT][STW];
 #pragma unroll
-                for (int k = 0; k < C::RING_FR; k++) rp[k * 64] = xb[k];
+        for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+            for (int i = 0; i < STW; i++) skip[bt][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- L dilated layers (nv_wavenet_reference.cpp:58-92) -------------------------------
+        for (int l = 0; l < L; l++) {
+            const frag* wl = wbase + (size_t)l * FLW * 64;
+            const frag* wn = wl + (size_t)FLW * 64;   // next layer, or the head after the last
+            const float* bl = biasLds + l * C::BIAS_L;
+            const int d = p.dil[l];
+            const bool havePrev = t >= d;
+
+            // full x as B fragments; x_l[t] replaces x_l[t-d] in the ring (same slot)
+            frag xb[BT][KF_R];
+            frag xp[BT][KF_R];
+            frag cd[BT][C::COND_FR];
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) {
+                lds_get_frags<F16, KF_R>(xbuf + bt * KF_R * 1024, lane, xb[bt]);
+#pragma unroll
+                for (int k = 0; k < KF_R; k++) {
+                    xp[bt][k] = xpN[bt][k];
+                    if (!havePrev) {
+#pragma unroll
+                        for (int e = 0; e < P::EPL; e++) xp[bt][k][e] = (elem)0.f;   // reference :287
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < C::COND_FR; k++) cd[bt][k] = cdN[bt][k];
+                frag* rp =
+                    ringBase + ((size_t)(tile0 + bt) * p.ringSlots + p.ringOff[l] + (t & (d - 1))) * KF_R * 64;
+#pragma unroll
+                for (int k = 0; k < KF_R; k++)
+                    if (k % NW == w) rp[k * 64] = xb[bt][k];
             }
 
-            // z = Wprev x[t-d] + Wcur x[t] + Bh + Lh
-            floatx4 acc[R2T];
+            // z = Wprev x[t-d] + Wcur x[t] + Bh + Lh for this wave's gate pairs:
+            // acc[2i] = tanh rows of tile w+NW*i, acc[2i+1] = sigmoid rows (tile + RT)
+            floatx4 acc[BT][2 * HTW];
 #pragma unroll
-            for (int i = 0; i < R2T; i++) acc[i] = *(const floatx4*)(bl + i * 16 + g * 4);
-            gemm<F16, PF, FL, R2T, C::KF_R>(ws, C::O_PREV, wl, wn, acc, xp);
-            gemm<F16, PF, FL, R2T, C::KF_R>(ws, C::O_CUR, wl, wn, acc, xb);
-            add_frags<F16, C::COND_CH>(acc, cd);
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int i = 0; i < HTW; i++) {
+                    acc[bt][2 * i] = *(const floatx4*)(bl + (w + NW * i) * 16 + g * 4);
+                    acc[bt][2 * i + 1] = *(const floatx4*)(bl + (w + NW * i + RT) * 16 + g * 4);
+                }
+            gemm<F16, PF, FLW, BT, 2 * HTW, KF_R>(ws, C::O_PREV, wl, wn, acc, xp);
+            gemm<F16, PF, FLW, BT, 2 * HTW, KF_R>(ws, C::O_CUR, wl, wn, acc, xb);
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                    for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cd[bt][k][e];
 
-            // gate
-            floatx4 h[RT];
+            // gate -> h tiles of this wave -> LDS
 #pragma unroll
-            for (int tt = 0; tt < RT; tt++)
+            for (int bt = 0; bt < BT; bt++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) h[tt][r] = tanh_t<F16>(acc[tt][r]) * sigmoid_f(acc[tt + RT][r]);
-            frag hb[C::KF_R];
-            to_bfrags<RT>(h, hb);
+                for (int i = 0; i < HTW; i++) {
+                    floatx4 hv;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        hv[r] = tanh_t<F16>(acc[bt][2 * i][r]) * sigmoid_f(acc[bt][2 * i + 1][r]);
+                    lds_put_tile<F16>(hbuf + bt * KF_R * 1024, w + NW * i, lane, hv);
+                }
 
             // prefetch the next layer's dilated input and conditioning (next sample's layer 0
-            // after the last layer); conditioning index is clamped at the end of the buffer.
-            {
-                int ln = l + 1, tn = t;
-                if (ln == L) { ln = 0; tn = t + 1; }
-                const int dn = p.dil[ln];
-                const frag* rp = ringBase + (size_t)(p.ringOff[ln] + (tn & (dn - 1))) * C::RING_FR * 64;
-#pragma unroll
-                for (int k = 0; k < C::RING_FR; k++) xpN[k] = rp[k * 64];
-                const int tc = tn < p.condSamples ? tn : p.condSamples - 1;
-                const frag* cp = condBase + (((size_t)tc * L + ln) * p.groups + grp) * C::COND_CH * 64;
-#pragma unroll
-                for (int k = 0; k < C::COND_CH; k++) cdN[k] = cp[k * 64];
-            }
+            // after the last layer)
+            if (l + 1 < L) prefetch(t, l + 1);
+            else prefetch(t + 1, 0);
 
-            // residual: x <- Wres h + Bres + x
-            floatx4 xa[RT];
+            wg_barrier();   // h complete
+            frag hb[BT][KF_R];
 #pragma unroll
-            for (int tt = 0; tt < RT; tt++) xa[tt] = *(const floatx4*)(bl + 2 * R + tt * 16 + g * 4) + x[tt];
-            gemm<F16, PF, FL, RT, C::KF_R>(ws, C::O_RES, wl, wn, xa, hb);
-#pragma unroll
-            for (int tt = 0; tt < RT; tt++) x[tt] = xa[tt];
+            for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(hbuf + bt * KF_R * 1024, lane, hb[bt]);
 
-            // skip: skip <- Wskip h + skip + Bskip
-            gemm<F16, PF, FL, ST, C::KF_R>(ws, C::O_SKIP, wl, wn, skip, hb);
+            // residual: x <- Wres h + Bres + x  (this wave's tiles) -> LDS
+            floatx4 xa[BT][HTW];
 #pragma unroll
-            for (int i = 0; i < ST; i++) skip[i] += *(const floatx4*)(bl + 3 * R + i * 16 + g * 4);
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int i = 0; i < HTW; i++)
+                    xa[bt][i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[bt][i];
+            gemm<F16, PF, FLW, BT, HTW, KF_R>(ws, C::O_RES, wl, wn, xa, hb);
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int i = 0; i < HTW; i++) {
+                    x[bt][i] = xa[bt][i];
+                    lds_put_tile<F16>(xbuf + bt * KF_R * 1024, w + NW * i, lane, xa[bt][i]);
+                }
 
-            if (dumpNow && valid) {
+            // skip: skip <- Wskip h + skip + Bskip (this wave's tiles); overlaps the x exchange
+            gemm<F16, PF, FLW, BT, STW, KF_R>(ws, C::O_SKIP, wl, wn, skip, hb);
 #pragma unroll
-                for (int tt = 0; tt < RT; tt++)
-                    *(floatx4*)(p.xtOut + ((size_t)l * p.maxBatch + b) * R + tt * 16 + g * 4) = x[tt];
-                const bool last = (l == L - 1);
+            for (int bt = 0; bt < BT; bt++)
 #pragma unroll
-                for (int i = 0; i < ST; i++) {
-                    floatx4 v = skip[i];
-                    if (last) {
+                for (int i = 0; i < STW; i++)
+                    skip[bt][i] += *(const floatx4*)(bl + 3 * R + (w + NW * i) * 16 + g * 4);
+
+            if (dumpNow) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
+                for (int bt = 0; bt < BT; bt++) {
+                    if (!uvalid[bt]) continue;
+                    const size_t bo = (size_t)l * p.maxBatch + ub[bt];
+#pragma unroll
+                    for (int i = 0; i < HTW; i++)
+                        *(floatx4*)(p.xtOut + bo * R + (w + NW * i) * 16 + g * 4) = x[bt][i];
+#pragma unroll
+                    for (int i = 0; i < STW; i++) {
+                        floatx4 v = skip[bt][i];
+                        if (l == L - 1) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
+                        }
+                        *(floatx4*)(p.skipOut + bo * S + (w + NW * i) * 16 + g * 4) = v;
                     }
-                    *(floatx4*)(p.skipOut + ((size_t)l * p.maxBatch + b) * S + i * 16 + g * 4) = v;
                 }
             }
+            wg_barrier();   // x complete
         }
 
-        // ---- output head (nv_wavenet_reference.cpp:94-104) -------------------------------
+        // ---- output head (nv_wavenet_reference.cpp:94-104) -----------------------------------
 #pragma unroll
-        for (int i = 0; i < ST; i++)
+        for (int bt = 0; bt < BT; bt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) skip[i][r] = __builtin_fmaxf(skip[i][r], 0.f);
-        frag sb[C::KF_S];
-        to_bfrags<ST>(skip, sb);
-
-        floatx4 zs[AT];
+            for (int i = 0; i < STW; i++) {
+                floatx4 v = skip[bt][i];
 #pragma unroll
-        for (int i = 0; i < AT; i++) zs[i] = *(const floatx4*)(ldsHead + i * 16 + g * 4);
-        gemm<F16, PF, FH, AT, C::KF_S>(ws, 0, whead, wbase, zs, sb);
+                for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
+                lds_put_tile<F16>(skbuf + bt * KF_S * 1024, w + NW * i, lane, v);
+            }
+        wg_barrier();
+        floatx4 zs[BT][ATW];
+        {
+            frag sb[BT][KF_S];
 #pragma unroll
-        for (int i = 0; i < AT; i++)
+            for (int bt = 0; bt < BT; bt++) {
+                lds_get_frags<F16, KF_S>(skbuf + bt * KF_S * 1024, lane, sb[bt]);
 #pragma unroll
-            for (int r = 0; r < 4; r++) zs[i][r] = __builtin_fmaxf(zs[i][r], 0.f);
-        if (dumpNow && valid) {
-#pragma unroll
-            for (int i = 0; i < AT; i++) *(floatx4*)(p.zs + (size_t)b * A + i * 16 + g * 4) = zs[i];
+                for (int i = 0; i < ATW; i++) zs[bt][i] = *(const floatx4*)(headBias + (w + NW * i) * 16 + g * 4);
+            }
+            gemm<F16, PF, FHW, BT, ATW, KF_S>(ws, 0, whead, wbase, zs, sb);
         }
-        frag zb[C::KF_A];
-        to_bfrags<AT>(zs, zb);
-
-        // logits, rows permuted so that lane g owns rows g*A/4 .. (g+1)*A/4-1 in register order
-        floatx4 za[AT];
 #pragma unroll
-        for (int i = 0; i < AT; i++) za[i] = *(const floatx4*)(ldsHead + A + g * (A / 4) + i * 4);
-        gemm<F16, PF, FH, AT, C::KF_A>(ws, C::F_ZS, whead, wbase, za, zb);
-
+        for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+            for (int i = 0; i < ATW; i++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) zs[bt][i][r] = __builtin_fmaxf(zs[bt][i][r], 0.f);
+                lds_put_tile<F16>(zsbuf + bt * KF_A * 1024, w + NW * i, lane, zs[bt][i]);
+                if (dumpNow && uvalid[bt])
+                    *(floatx4*)(p.zs + (size_t)ub[bt] * A + (w + NW * i) * 16 + g * 4) = zs[bt][i];
+            }
+        wg_barrier();
+        {
+            floatx4 za[BT][ATW];
+            frag zb[BT][KF_A];
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) {
+                lds_get_frags<F16, KF_A>(zsbuf + bt * KF_A * 1024, lane, zb[bt]);
+#pragma unroll
+                for (int i = 0; i < ATW; i++)
+                    za[bt][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
+            }
+            gemm<F16, PF, FHW, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, za, zb);
+            // logits -> LDS [utt][row] (row stride padded by 4 floats: conflict-free b128 writes)
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int i = 0; i < ATW; i++) {
+                    *(floatx4*)(lgbuf + (bt * 16 + j) * C::LROW + (w + NW * i) * 16 + g * 4) = za[bt][i];
+                    if (dumpNow && uvalid[bt])
+                        *(floatx4*)(p.za + (size_t)ub[bt] * A + (w + NW * i) * 16 + g * 4) = za[bt][i];
+                }
+        }
         // the head is not a multiple of the ring: rotate the ring back into phase
-        if constexpr (FH % PF != 0) {
+        if constexpr (FHW % PF != 0) {
             frag tmp[PF];
 #pragma unroll
-            for (int i = 0; i < PF; i++) tmp[i] = ws.buf[(i + FH) % PF];
+            for (int i = 0; i < PF; i++) tmp[i] = ws.buf[(i + FHW) % PF];
 #pragma unroll
             for (int i = 0; i < PF; i++) ws.buf[i] = tmp[i];
         }
-
-        if (dumpNow && valid) {
-#pragma unroll
-            for (int i = 0; i < AT; i++) *(floatx4*)(p.za + (size_t)b * A + g * (A / 4) + i * 4) = za[i];
-        }
+        wg_barrier();
 
         // ---- softmax + inverse-CDF pick (softmax.cuh:36-191; oracle matrix.cpp:166-183,
-        //      nv_wavenet_reference.cpp:106-121) ------------------------------------------
-        float m = za[0][0];
+        //      nv_wavenet_reference.cpp:106-121): LPU lanes per utterance, RPL rows per lane ----
 #pragma unroll
-        for (int i = 0; i < AT; i++)
+        for (int bt = 0; bt < BT; bt++) {
+            float e[C::RPL];
+            const float* lrow = lgbuf + (bt * 16 + su) * C::LROW + sq * C::RPL;
 #pragma unroll
-            for (int r = 0; r < 4; r++) m = __builtin_fmaxf(m, za[i][r]);
-        m = __builtin_fmaxf(m, __shfl_xor(m, 16));
-        m = __builtin_fmaxf(m, __shfl_xor(m, 32));
-        float lsum = 0.f;
+            for (int i = 0; i < C::RPL / 4; i++) {
+                floatx4 v = *(const floatx4*)(lrow + i * 4);
 #pragma unroll
-        for (int i = 0; i < AT; i++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float e = fast_exp(za[i][r] - m);
-                za[i][r] = e;
-                lsum += e;
+                for (int r = 0; r < 4; r++) e[i * 4 + r] = v[r];
             }
-        const float u = __shfl_xor(lsum, 16);
-        const float ps = lsum + u;
-        const float v = __shfl_xor(ps, 32);
-        const float total = ps + v;
-        const float prefix = ((g & 1) ? u : 0.f) + ((g & 2) ? v : 0.f);
-        const float target = selv * total;
-        float cum = prefix;
-        int cnt = 0;
+            float m = e[0];
 #pragma unroll
-        for (int i = 0; i < AT; i++)
+            for (int i = 1; i < C::RPL; i++) m = __builtin_fmaxf(m, e[i]);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                cum += za[i][r];
-                cnt += (cum <= target) ? 1 : 0;   // oracle picks the first row with sel < cumsum
+            for (int o = 1; o < C::LPU; o <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+            float lsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < C::RPL; i++) {
+                e[i] = fast_exp(e[i] - m);
+                lsum += e[i];
             }
-        if (dumpNow && valid) {
-            const float inv = 1.0f / total;
+            // inclusive scan of the lane sums over the LPU lanes of this utterance
+            float incl = lsum;
 #pragma unroll
-            for (int i = 0; i < AT; i++) *(floatx4*)(p.p + (size_t)b * A + g * (A / 4) + i * 4) = za[i] * inv;
+            for (int o = 1; o < C::LPU; o <<= 1) {
+                float up = __shfl_up(incl, o);
+                if (sq >= o) incl += up;
+            }
+            const float total = __shfl(incl, (lane & ~(C::LPU - 1)) + C::LPU - 1);
+            const float target = selv[bt] * total;
+            // first row of this lane whose cumulative sum exceeds the target
+            // (the oracle picks the first row with sel < cumsum)
+            float cum = incl - lsum;   // exclusive prefix of this lane
+            int first = C::RPL;
+#pragma unroll
+            for (int i = 0; i < C::RPL; i++) {
+                cum += e[i];
+                first = (first == C::RPL && target < cum) ? i : first;
+            }
+            int pick = first < C::RPL ? sq * C::RPL + first : 0x7fffffff;
+#pragma unroll
+            for (int o = 1; o < C::LPU; o <<= 1) {
+                int other = __shfl_xor(pick, o);
+                pick = other < pick ? other : pick;
+            }
+            if (pick >= A) pick = 128;             // scan fell off the end (softmax.cuh:154-155)
+            const int sb = (tile0 + bt) * 16 + su;
+            if (sq == 0) {
+                ybuf[bt * 16 + su] = pick;
+                if (sb < p.batch) p.yOut[(size_t)sb * p.numSamples + t] = pick;
+            }
+            if (dumpNow && sb < p.batch) {
+                const float inv = 1.0f / total;
+#pragma unroll
+                for (int i = 0; i < C::RPL / 4; i++)
+                    *(floatx4*)(p.p + (size_t)sb * A + sq * C::RPL + i * 4) =
+                        floatx4{e[i * 4] * inv, e[i * 4 + 1] * inv, e[i * 4 + 2] * inv, e[i * 4 + 3] * inv};
+            }
         }
-        // lanes g=0..3 of a column hold consecutive row ranges: a lane counts only if all before are full
-        const int c1 = __shfl_xor(cnt, 16);
-        const int c0 = (g & 1) ? c1 : cnt;        // count of the even lane of my pair
-        const int cO = (g & 1) ? cnt : c1;        // count of the odd lane of my pair
-        const int pairCnt = c0 + (c0 == A / 4 ? cO : 0);
-        const int pairOther = __shfl_xor(pairCnt, 32);
-        const int lo = (g & 2) ? pairOther : pairCnt;
-        const int hi = (g & 2) ? pairCnt : pairOther;
-        int y = lo + (lo == A / 2 ? hi : 0);
-        if (y >= A) y = 128;                      // scan fell off the end (softmax.cuh:154-155)
-
-        if (valid && g == 0) p.yOut[(size_t)b * p.numSamples + t] = y;
-        yPrev = yCur;
-        yCur = y;
+        wg_barrier();
+#pragma unroll
+        for (int bt = 0; bt < BT; bt++) {
+            yPrev[bt] = yCur[bt];
+            yCur[bt] = ybuf[bt * 16 + j];
+        }
+        // ybuf / lgbuf are next written after several barriers of the next sample
     }
 
-    if (valid && g == 0) {
-        p.yInPrev[b] = yPrev;
-        p.yInCur[b] = yCur;
+    if (w == 0 && g == 0) {
+#pragma unroll
+        for (int bt = 0; bt < BT; bt++)
+            if (uvalid[bt]) {
+                p.yInPrev[ub[bt]] = yPrev[bt];
+                p.yInCur[ub[bt]] = yCur[bt];
+            }
     }
 }
 
@@ -525,22 +656,31 @@ __global__ __launch_bounds__(64, 1) void wavenet_wave16(const Params p) {
 // pack kernels (setup only; role of nv_wavenet_conversions.cuh + matrix_math.cuh:55-64)
 // ------------------------------------------------------------------------------------------
 
-// fp32 col-major M x K  ->  fragments, see header. One thread per destination element.
+// fp32 col-major M x K -> per-wave fragment streams.  Wave w gets the tiles t = w + NW*i in
+// order (gateRT=0), or for the gated 2R x R matrices the pairs (t, t+RT) (gateRT=RT>0).
+// dst + w*waveStride is the start of this matrix inside wave w's stream.
 template <bool F16>
-__global__ void pack_weight_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src,
-                                   int M, int K, int rowperm) {
+__global__ void pack_weight_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src, int M,
+                                   int K, int NW, size_t waveStride, int gateRT) {
     constexpr int EPL = Prec<F16>::EPL, TPF = Prec<F16>::TPF;
     const int KF = K / (16 * TPF);
+    const int tilesPerWave = M / 16 / NW;
+    const size_t perWave = (size_t)tilesPerWave * KF * 64 * EPL;
     const size_t n = (size_t)M * K;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx % EPL;
-        const int lane = (idx / EPL) % 64;
-        const int f = idx / (EPL * 64);
-        const int mt = f / KF, kf = f % KF;
+        const int w = idx / perWave;
+        size_t r = idx % perWave;
+        const int e = r % EPL; r /= EPL;
+        const int lane = r % 64; r /= 64;
+        const int kf = r % KF;
+        const int it = r / KF;                         // tile slot inside the wave's list
+        int tile;
+        if (gateRT > 0) tile = w + NW * (it >> 1) + (it & 1) * gateRT;
+        else tile = w + NW * it;
         const int i = lane & 15, g = lane >> 4;
-        const int m = rowperm ? ((i >> 2) * (M / 4) + mt * 4 + (i & 3)) : (mt * 16 + i);
+        const int m = tile * 16 + i;
         const int k = (kf * TPF + (e >> 2)) * 16 + g * 4 + (e & 3);
-        dst[idx] = (typename Prec<F16>::elem)src[(size_t)m + (size_t)k * M];
+        dst[(size_t)w * waveStride + (idx % perWave)] = (typename Prec<F16>::elem)src[(size_t)m + (size_t)k * M];
     }
 }
 
@@ -551,26 +691,31 @@ __global__ void convert_kernel(typename Prec<F16>::elem* __restrict__ dst, const
         dst[i] = (typename Prec<F16>::elem)src[i];
 }
 
-// conditioning: fp32 [samples][L][maxBatch][2R]  ->  [samples][L][groups][chunk][lane][EPL]
+// conditioning: fp32 [rows = samples*L][maxBatch][2R] -> [rows][tiles][wave][COND_FR][lane][EPL]
+// fragment c, element e of wave w: gate slot it = c*TPF + (e>>2) -> tile = w + NW*(it>>1) + (it&1)*RT
 template <bool F16>
 __global__ void pack_cond_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src,
-                                 size_t rows /* samples*L */, int maxBatch, int groups, int R2) {
+                                 size_t rows, int maxBatch, int tiles, int R, int NW) {
     constexpr int EPL = Prec<F16>::EPL, TPF = Prec<F16>::TPF;
-    const int CH = R2 / (16 * TPF);
-    const size_t perRow = (size_t)groups * CH * 64 * EPL;
+    const int RT = R / 16;
+    const int CF = 2 * (RT / NW) / TPF;
+    const size_t perRow = (size_t)tiles * NW * CF * 64 * EPL;
     const size_t n = rows * perRow;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t row = idx / perRow;
         size_t r = idx % perRow;
         const int e = r % EPL; r /= EPL;
         const int lane = r % 64; r /= 64;
-        const int c = r % CH;
-        const int grp = r / CH;
+        const int c = r % CF; r /= CF;
+        const int w = r % NW;
+        const int tl = r / NW;
         const int j = lane & 15, g = lane >> 4;
-        const int b = grp * 16 + j;
-        const int ch = (c * TPF + (e >> 2)) * 16 + g * 4 + (e & 3);
+        const int b = tl * 16 + j;
+        const int it = c * TPF + (e >> 2);
+        const int tile = w + NW * (it >> 1) + (it & 1) * RT;
+        const int ch = tile * 16 + g * 4 + (e & 3);
         float v = 0.f;
-        if (b < maxBatch) v = src[(row * maxBatch + b) * R2 + ch];
+        if (b < maxBatch) v = src[(row * maxBatch + b) * 2 * R + ch];
         dst[idx] = (typename Prec<F16>::elem)v;
     }
 }
