@@ -1,0 +1,57 @@
+"""Multi-GPU batch sharding for the inference engine.
+
+Utterances are independent (no cross-utterance term anywhere: every kernel of the reference
+indexes by batch_offset, nv_wavenet_singleblock.cuh:70, nv_wavenet_persistent.cuh:110), so the
+batch shards with no data-path collective: rank g of G generates utterances
+[g*B/G, (g+1)*B/G) on its own GPU with replicated weights, and ONE collective at the end gathers
+the [B/G][N] int32 sample blocks, which are contiguous row ranges of the [B][N] output
+(SURVEY.md 8e).  The reference itself is single-GPU; this is the added multi-GPU path of
+BASELINE.json configs[4] (batch 64 = 8 x 8).  Backend "nccl" is RCCL on ROCm; "gloo" on CPU.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_batch, world_size, rank):
+    """Contiguous, balanced split: the first (total % world) ranks get one extra utterance."""
+    base, extra = divmod(total_batch, world_size)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def shard_inputs(Lh, sel, world_size, rank):
+    """Slice conditioning [N][L][B][2R] and selectors [N][B] along the batch axis for this rank.
+    Works on numpy arrays and torch tensors; returns contiguous copies."""
+    B = Lh.shape[2]
+    s, n = shard_range(B, world_size, rank)
+    if isinstance(Lh, np.ndarray):
+        return np.ascontiguousarray(Lh[:, :, s:s + n]), np.ascontiguousarray(sel[:, s:s + n])
+    return Lh[:, :, s:s + n].contiguous(), sel[:, s:s + n].contiguous()
+
+
+def gather_samples(y_local, total_batch, group=None, async_op=False):
+    """All ranks contribute their [b_local][N] int32 block; every rank receives the [B][N] result
+    (one all_gather over RCCL/xGMI: 4*B*N bytes in total). Ragged shards are padded to the
+    largest shard for the collective and trimmed afterwards.
+    Returns (y_full, None), or (None, finish) with async_op=True: call finish() for the result."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    N = y_local.shape[1]
+    sizes = [shard_range(total_batch, world, r)[1] for r in range(world)]
+    assert y_local.shape[0] == sizes[rank]
+    mx = max(sizes)
+    if y_local.shape[0] != mx:
+        pad = torch.zeros(mx - y_local.shape[0], N, dtype=y_local.dtype, device=y_local.device)
+        y_local = torch.cat([y_local, pad], 0)
+    out = torch.empty(world * mx, N, dtype=y_local.dtype, device=y_local.device)
+    work = dist.all_gather_into_tensor(out, y_local.contiguous(), group=group, async_op=async_op)
+
+    def finish():
+        if work is not None:
+            work.wait()
+        if all(s == mx for s in sizes):
+            return out
+        return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], 0)
+
+    return (None, finish) if async_op else (finish(), None)
