@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwavenet_infer.so")
+LIB_PATH = os.environ.get("NVW_LIB") or os.path.join(_HERE, "libwavenet_infer.so")  # NVW_LIB: timing experiments
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

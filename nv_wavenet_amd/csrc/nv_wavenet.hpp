@@ -65,7 +65,7 @@ protected:
     elem* m_cond;       // packed conditioning
     float* m_outputSelectors;
     elem* m_ring;
-    int *m_dil, *m_ringOff;
+    int m_dil[wn::kMaxLayers], m_ringOff[wn::kMaxLayers];
     int *m_yInPrev, *m_yInCur, *m_yOut;
     float *m_XtOut, *m_skipOut, *m_Zs, *m_Za, *m_p;
 
@@ -145,20 +145,17 @@ public:
         }
 
         // dilation schedule (nv_wavenet.cuh:99,110-111): d doubles per layer, back to 1 past maxDilation
-        std::vector<int> dil(numLayers), off(numLayers);
+        assert(numLayers <= wn::kMaxLayers);
         int d = 1, slots = 0;
+        for (int l = 0; l < wn::kMaxLayers; l++) m_dil[l] = 1, m_ringOff[l] = 0;
         for (int l = 0; l < numLayers; l++) {
-            dil[l] = d;
-            off[l] = slots;
+            m_dil[l] = d;
+            m_ringOff[l] = slots;
             slots += d;
             d <<= 1;
             if (d > maxDilation) d = 1;
         }
         m_ringSlots = slots;
-        gpuErrChk(hipMalloc(&m_dil, numLayers * sizeof(int)));
-        gpuErrChk(hipMalloc(&m_ringOff, numLayers * sizeof(int)));
-        gpuErrChk(hipMemcpy(m_dil, dil.data(), numLayers * sizeof(int), hipMemcpyHostToDevice));
-        gpuErrChk(hipMemcpy(m_ringOff, off.data(), numLayers * sizeof(int), hipMemcpyHostToDevice));
 
         const size_t wElems = (size_t)C::NW * C::waveStreamFrags(numLayers) * C::FRAG_ELEMS;
         gpuErrChk(hipMalloc(&m_wblob, wElems * sizeof(elem)));
@@ -171,7 +168,7 @@ public:
         gpuErrChk(hipMemset(m_embedPrev, 0, (size_t)A * R * sizeof(elem)));
         gpuErrChk(hipMemset(m_embedCur, 0, (size_t)A * R * sizeof(elem)));
 
-        const size_t condElems = (size_t)numSamples * numLayers * m_tiles * 16 * 2 * R;
+        const size_t condElems = (size_t)(numSamples + 1) * numLayers * m_tiles * 16 * 2 * R;   // + one padding sample
         gpuErrChk(hipMalloc(&m_cond, condElems * sizeof(elem)));
         gpuErrChk(hipMemset(m_cond, 0, condElems * sizeof(elem)));
         gpuErrChk(hipMalloc(&m_outputSelectors, (size_t)numSamples * batchSize * sizeof(float)));
@@ -212,8 +209,6 @@ public:
 
     virtual ~nvWavenetInfer() {
         gpuErrChk(hipDeviceSynchronize());
-        gpuErrChk(hipFree(m_dil));
-        gpuErrChk(hipFree(m_ringOff));
         gpuErrChk(hipFree(m_wblob));
         gpuErrChk(hipFree(m_bias));
         gpuErrChk(hipFree(m_embedPrev));
@@ -374,8 +369,7 @@ public:
         p.cond = m_cond;
         p.sel = m_outputSelectors;
         p.ring = m_ring;
-        p.dil = m_dil;
-        p.ringOff = m_ringOff;
+        for (int l = 0; l < wn::kMaxLayers; l++) p.dil[l] = m_dil[l], p.ringOff[l] = m_ringOff[l];
         p.yInPrev = m_yInPrev;
         p.yInCur = m_yInCur;
         p.yOut = m_yOut;

@@ -120,6 +120,8 @@ struct Cfg {
     __host__ __device__ static size_t waveStreamFrags(int L) { return (size_t)L * FLW + FHW; }
 };
 
+constexpr int kMaxLayers = 128;
+
 // Everything the kernel needs, passed by value (role of nv_wavenet_params, nv_wavenet.cuh:40-85).
 struct Params {
     const void* wblob;       // NW per-wave streams: [L][FLW] layer fragments then [FHW] head fragments
@@ -129,8 +131,8 @@ struct Params {
     const void* cond;        // [sample][L][tile][wave][COND_FR] fragments
     const float* sel;        // [N][maxBatch] uniform draws
     void* ring;              // [tile][ringSlots][KF_R] fragments
-    const int* dil;          // [L] dilation of layer l
-    const int* ringOff;      // [L] first ring slot of layer l
+    int dil[kMaxLayers];     // dilation of layer l       (by value: read with scalar loads, so a
+    int ringOff[kMaxLayers]; // first ring slot of layer l  use never waits on the weight stream)
     int* yInPrev;            // [maxBatch]
     int* yInCur;             // [maxBatch]
     int* yOut;               // [batch][numSamples]
@@ -143,7 +145,7 @@ struct Params {
     int batch;               // utterances to generate (<= maxBatch)
     int maxBatch;            // batch stride of sel / dumps
     int numSamples;          // row stride of yOut
-    int condSamples;         // samples held in cond / sel (maxSamples)
+    int condSamples;         // samples held in cond / sel (maxSamples); cond has one padding sample more
     int initSample;
     int count;               // samples generated by this launch
     int ringSlots;           // sum of dilations
@@ -160,7 +162,11 @@ WN_DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088
 WN_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // sigmoid: relative error of a few ulp (no cancellation)
+#ifndef WN_ABL_NOACT
 WN_DEV float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+#else
+WN_DEV float sigmoid_f(float x) { return x; }
+#endif
 
 // tanh, fp16 engine: result is rounded to fp16 afterwards, 1 - 2/(e^2x+1) is ample.
 WN_DEV float tanh_fast(float x) {
@@ -184,7 +190,11 @@ WN_DEV float tanh_acc(float x) {
     big = __builtin_copysignf(big, x);
     return a < 0.55f ? small : big;
 }
+#ifndef WN_ABL_NOACT
 template <bool F16> WN_DEV float tanh_t(float x) { return F16 ? tanh_fast(x) : tanh_acc(x); }
+#else
+template <bool F16> WN_DEV float tanh_t(float x) { return x; }
+#endif
 
 WN_DEV floatx4 mma(half8 a, half8 b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -201,7 +211,11 @@ WN_DEV floatx4 quad_to_f32(floatx4 q) { return q; }
 // Workgroup barrier that does NOT wait for outstanding global loads (the weight prefetch ring
 // stays in flight across it): only this wave's LDS traffic is drained. __syncthreads() would emit
 // s_waitcnt vmcnt(0) as well.
+#ifndef WN_ABL_NOBARRIER
 WN_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
+WN_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
 
 // ---- LDS exchange of activations as B fragments -------------------------------------------
 // tile t of a vector, held in MFMA D layout (fp32), goes to its place in the fragment image
@@ -230,25 +244,30 @@ template <bool F16, int PF> struct WStream {
 // unrolling) and refill its ring slot with fragment idx+PF: from the current body while that is
 // inside it (BODY fragments long), otherwise from `next` (the body that follows in the stream).
 template <bool F16, int PF, int BODY>
-WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const typename Prec<F16>::frag* cur,
-                                     const typename Prec<F16>::frag* next) {
+WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const char* cur, const char* next,
+                                     unsigned laneOff) {
     using frag = typename Prec<F16>::frag;
     frag a = ws.buf[idx % PF];
     int nidx = idx + PF;
-    ws.buf[idx % PF] = (nidx < BODY) ? cur[(size_t)nidx * 64] : next[(size_t)(nidx - BODY) * 64];
+#ifndef WN_ABL_NOWEIGHTLOAD
+    // cur / next are wave-uniform (SGPR base), laneOff = lane*16: one SALU add per fragment at most
+    const char* src = (nidx < BODY) ? cur + (size_t)nidx * 1024 : next + (size_t)(nidx - BODY) * 1024;
+    ws.buf[idx % PF] = *(const frag*)(src + laneOff);
+#else
+    (void)nidx; (void)cur; (void)next; (void)laneOff;
+#endif
     return a;
 }
 
 // acc[bt][mt] += W(tile mt) * b[bt]   for MT tiles of this wave, KF k-fragments, BT batch tiles
 template <bool F16, int PF, int BODY, int BT, int MT, int KF>
-WN_DEV void gemm(WStream<F16, PF>& ws, int pos0, const typename Prec<F16>::frag* cur,
-                 const typename Prec<F16>::frag* next, floatx4 (&acc)[BT][MT],
-                 const typename Prec<F16>::frag (&b)[BT][KF]) {
+WN_DEV void gemm(WStream<F16, PF>& ws, int pos0, const char* cur, const char* next, unsigned laneOff,
+                 floatx4 (&acc)[BT][MT], const typename Prec<F16>::frag (&b)[BT][KF]) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
         for (int kf = 0; kf < KF; kf++) {
-            auto a = take<F16, PF, BODY>(ws, pos0 + mt * KF + kf, cur, next);
+            auto a = take<F16, PF, BODY>(ws, pos0 + mt * KF + kf, cur, next, laneOff);
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) acc[bt][mt] = mma(a, b[bt][kf], acc[bt][mt]);
         }
@@ -303,13 +322,24 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         for (int i = tid; i < nb; i += C::THREADS) biasLds[i] = p.bias[i];
     }
     const float* const headBias = biasLds + L * C::BIAS_L;
+    // The skip accumulator is only touched by MFMAs inside the layer loop: the per-layer skip biases
+    // are turned into running sums here (slot of layer l := Bskip_0 + ... + Bskip_l, added in layer
+    // order like the oracle does) and added once, at the head and in the per-layer dumps.
+    __syncthreads();
+    for (int s0 = tid; s0 < S; s0 += C::THREADS) {
+        float run = biasLds[3 * R + s0];
+        for (int l = 1; l < L; l++) {
+            run += biasLds[l * C::BIAS_L + 3 * R + s0];
+            biasLds[l * C::BIAS_L + 3 * R + s0] = run;
+        }
+    }
 
-    const frag* const wbase = (const frag*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 64 + lane;
-    const frag* const whead = wbase + (size_t)L * FLW * 64;
+    const unsigned laneOff = (unsigned)lane * 16u;
+    // wave-uniform byte bases (SGPRs); per-lane part is laneOff
+    const char* const wbase = (const char*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 1024;
+    const char* const whead = wbase + (size_t)L * FLW * 1024;
     const elem* const embPrev = (const elem*)p.embPrev;
     const elem* const embCur = (const elem*)p.embCur;
-    const frag* const condBase = (const frag*)p.cond + lane;
-    frag* const ringBase = (frag*)p.ring + lane;
 
     int yPrev[BT], yCur[BT];
     floatx4 ep[BT][HTW];      // embedding row of the older tap, known one sample early
@@ -325,29 +355,52 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     // ---- prime the weight ring ----------------------------------------------------------------
     WStream<F16, PF> ws;
 #pragma unroll
-    for (int i = 0; i < PF; i++) ws.buf[i] = wbase[(size_t)i * 64];
+    for (int i = 0; i < PF; i++) ws.buf[i] = *(const frag*)(wbase + (size_t)i * 1024 + laneOff);
 
     // ---- prefetch of the dilated input + conditioning of (sample tn, layer ln) ----------------
     frag xpN[BT][KF_R];
     frag cdN[BT][C::COND_FR];
+    // per-(sample,layer) strides in bytes; everything here is wave-uniform (SALU)
+    const size_t condStride = (size_t)p.tiles * NW * C::COND_FR * 1024;            // one (sample,layer) row
+    const char* const condMine = (const char*)p.cond + ((size_t)tile0 * NW + w) * C::COND_FR * 1024;
+    const size_t ringTile = (size_t)p.ringSlots * KF_R * 1024;
+    char* const ringMine = (char*)p.ring + (size_t)tile0 * ringTile;
     auto prefetch = [&](int tn, int ln) {
+#ifdef WN_ABL_NOPREFETCH
+        if (tn != p.initSample || ln != 0) return;
+#endif
         const int dn = p.dil[ln];
-        const int tc = tn < p.condSamples ? tn : p.condSamples - 1;
+        const unsigned slot = (unsigned)(p.ringOff[ln] + (tn & (dn - 1)));
+        const char* rp0 = ringMine + (size_t)slot * (KF_R * 1024);
+        // the conditioning buffer carries one padding sample, so (t+1, 0) is always in bounds
+        const char* cp0 = condMine + ((size_t)tn * L + ln) * condStride;
 #pragma unroll
         for (int bt = 0; bt < BT; bt++) {
-            const frag* rp =
-                ringBase + ((size_t)(tile0 + bt) * p.ringSlots + p.ringOff[ln] + (tn & (dn - 1))) * KF_R * 64;
 #pragma unroll
-            for (int k = 0; k < KF_R; k++) xpN[bt][k] = rp[k * 64];
-            const frag* cp = condBase + ((((size_t)tc * L + ln) * p.tiles + tile0 + bt) * NW + w) * C::COND_FR * 64;
+            for (int k = 0; k < KF_R; k++) xpN[bt][k] = *(const frag*)(rp0 + bt * ringTile + k * 1024 + laneOff);
 #pragma unroll
-            for (int k = 0; k < C::COND_FR; k++) cdN[bt][k] = cp[k * 64];
+            for (int k = 0; k < C::COND_FR; k++)
+                cdN[bt][k] = *(const frag*)(cp0 + (size_t)bt * NW * C::COND_FR * 1024 + k * 1024 + laneOff);
         }
     };
     prefetch(p.initSample, 0);
 
     __syncthreads();   // bias table visible
 
+#ifdef WN_TIMING
+    // experiment build only: per-phase shader-clock sums of wave 0, written to p.p[0..15]
+    unsigned long long tacc[12] = {0};
+    unsigned long long tmark = 0;
+#define WN_TMARK(i)                                                        \
+    {                                                                      \
+        unsigned long long _n = __builtin_amdgcn_s_memtime();              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
+        tacc[i] += _n - tmark;                                             \
+        tmark = _n;                                                        \
+    }
+#else
+#define WN_TMARK(i)
+#endif
     const int tEnd = p.initSample + p.count;
     for (int t = p.initSample; t < tEnd; t++) {
         const bool dumpNow = p.dump && (t == tEnd - 1);
@@ -362,6 +415,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         }
 
         // ---- embedding (nv_wavenet_reference.cpp:42-56): each wave makes its own x tiles ------
+        WN_TMARK(11)
         floatx4 x[BT][HTW];
 #pragma unroll
         for (int bt = 0; bt < BT; bt++) {
@@ -382,6 +436,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 ep[bt][i] = quad_to_f32(*(const quad*)(embPrev + (size_t)yCur[bt] * R + (w + NW * i) * 16 + g * 4));
         }
         wg_barrier();
+        WN_TMARK(0)
 
         floatx4 skip[BT][STW];
 #pragma unroll
@@ -391,8 +446,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 
         // ---- L dilated layers (nv_wavenet_reference.cpp:58-92) -------------------------------
         for (int l = 0; l < L; l++) {
-            const frag* wl = wbase + (size_t)l * FLW * 64;
-            const frag* wn = wl + (size_t)FLW * 64;   // next layer, or the head after the last
+            const char* wl = wbase + (size_t)l * FLW * 1024;
+            const char* wn = wl + (size_t)FLW * 1024;   // next layer, or the head after the last
             const float* bl = biasLds + l * C::BIAS_L;
             const int d = p.dil[l];
             const bool havePrev = t >= d;
@@ -414,11 +469,10 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 }
 #pragma unroll
                 for (int k = 0; k < C::COND_FR; k++) cd[bt][k] = cdN[bt][k];
-                frag* rp =
-                    ringBase + ((size_t)(tile0 + bt) * p.ringSlots + p.ringOff[l] + (t & (d - 1))) * KF_R * 64;
+                char* rp = ringMine + bt * ringTile + (size_t)(unsigned)(p.ringOff[l] + (t & (d - 1))) * (KF_R * 1024);
 #pragma unroll
                 for (int k = 0; k < KF_R; k++)
-                    if (k % NW == w) rp[k * 64] = xb[bt][k];
+                    if (k % NW == w) *(frag*)(rp + k * 1024 + laneOff) = xb[bt][k];
             }
 
             // z = Wprev x[t-d] + Wcur x[t] + Bh + Lh for this wave's gate pairs:
@@ -431,8 +485,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     acc[bt][2 * i] = *(const floatx4*)(bl + (w + NW * i) * 16 + g * 4);
                     acc[bt][2 * i + 1] = *(const floatx4*)(bl + (w + NW * i + RT) * 16 + g * 4);
                 }
-            gemm<F16, PF, FLW, BT, 2 * HTW, KF_R>(ws, C::O_PREV, wl, wn, acc, xp);
-            gemm<F16, PF, FLW, BT, 2 * HTW, KF_R>(ws, C::O_CUR, wl, wn, acc, xb);
+            WN_TMARK(1)
+            gemm<F16, PF, FLW, BT, 2 * HTW, KF_R>(ws, C::O_PREV, wl, wn, laneOff, acc, xp);
+            gemm<F16, PF, FLW, BT, 2 * HTW, KF_R>(ws, C::O_CUR, wl, wn, laneOff, acc, xb);
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
@@ -452,12 +507,15 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     lds_put_tile<F16>(hbuf + bt * KF_R * 1024, w + NW * i, lane, hv);
                 }
 
+            WN_TMARK(2)
             // prefetch the next layer's dilated input and conditioning (next sample's layer 0
             // after the last layer)
             if (l + 1 < L) prefetch(t, l + 1);
             else prefetch(t + 1, 0);
 
+            WN_TMARK(3)
             wg_barrier();   // h complete
+            WN_TMARK(4)
             frag hb[BT][KF_R];
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(hbuf + bt * KF_R * 1024, lane, hb[bt]);
@@ -469,7 +527,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int i = 0; i < HTW; i++)
                     xa[bt][i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[bt][i];
-            gemm<F16, PF, FLW, BT, HTW, KF_R>(ws, C::O_RES, wl, wn, xa, hb);
+            gemm<F16, PF, FLW, BT, HTW, KF_R>(ws, C::O_RES, wl, wn, laneOff, xa, hb);
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
@@ -478,13 +536,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     lds_put_tile<F16>(xbuf + bt * KF_R * 1024, w + NW * i, lane, xa[bt][i]);
                 }
 
+            WN_TMARK(5)
             // skip: skip <- Wskip h + skip + Bskip (this wave's tiles); overlaps the x exchange
-            gemm<F16, PF, FLW, BT, STW, KF_R>(ws, C::O_SKIP, wl, wn, skip, hb);
-#pragma unroll
-            for (int bt = 0; bt < BT; bt++)
-#pragma unroll
-                for (int i = 0; i < STW; i++)
-                    skip[bt][i] += *(const floatx4*)(bl + 3 * R + (w + NW * i) * 16 + g * 4);
+            gemm<F16, PF, FLW, BT, STW, KF_R>(ws, C::O_SKIP, wl, wn, laneOff, skip, hb);
 
             if (dumpNow) {
 #pragma unroll
@@ -496,7 +550,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         *(floatx4*)(p.xtOut + bo * R + (w + NW * i) * 16 + g * 4) = x[bt][i];
 #pragma unroll
                     for (int i = 0; i < STW; i++) {
-                        floatx4 v = skip[bt][i];
+                        floatx4 v = skip[bt][i] + *(const floatx4*)(bl + 3 * R + (w + NW * i) * 16 + g * 4);
                         if (l == L - 1) {
 #pragma unroll
                             for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
@@ -505,7 +559,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     }
                 }
             }
+            WN_TMARK(6)
             wg_barrier();   // x complete
+            WN_TMARK(7)
         }
 
         // ---- output head (nv_wavenet_reference.cpp:94-104) -----------------------------------
@@ -513,7 +569,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         for (int bt = 0; bt < BT; bt++)
 #pragma unroll
             for (int i = 0; i < STW; i++) {
-                floatx4 v = skip[bt][i];
+                floatx4 v = skip[bt][i] +
+                            *(const floatx4*)(biasLds + (L - 1) * C::BIAS_L + 3 * R + (w + NW * i) * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
                 lds_put_tile<F16>(skbuf + bt * KF_S * 1024, w + NW * i, lane, v);
@@ -528,7 +585,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int i = 0; i < ATW; i++) zs[bt][i] = *(const floatx4*)(headBias + (w + NW * i) * 16 + g * 4);
             }
-            gemm<F16, PF, FHW, BT, ATW, KF_S>(ws, 0, whead, wbase, zs, sb);
+            gemm<F16, PF, FHW, BT, ATW, KF_S>(ws, 0, whead, wbase, laneOff, zs, sb);
         }
 #pragma unroll
         for (int bt = 0; bt < BT; bt++)
@@ -551,7 +608,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 for (int i = 0; i < ATW; i++)
                     za[bt][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
             }
-            gemm<F16, PF, FHW, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, za, zb);
+            gemm<F16, PF, FHW, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zb);
             // logits -> LDS [utt][row] (row stride padded by 4 floats: conflict-free b128 writes)
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
@@ -562,6 +619,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         *(floatx4*)(p.za + (size_t)ub[bt] * A + (w + NW * i) * 16 + g * 4) = za[bt][i];
                 }
         }
+        WN_TMARK(8)
         // the head is not a multiple of the ring: rotate the ring back into phase
         if constexpr (FHW % PF != 0) {
             frag tmp[PF];
@@ -571,6 +629,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             for (int i = 0; i < PF; i++) ws.buf[i] = tmp[i];
         }
         wg_barrier();
+        WN_TMARK(9)
 
         // ---- softmax + inverse-CDF pick (softmax.cuh:36-191; oracle matrix.cpp:166-183,
         //      nv_wavenet_reference.cpp:106-121): LPU lanes per utterance, RPL rows per lane ----
@@ -640,7 +699,12 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             yCur[bt] = ybuf[bt * 16 + j];
         }
         // ybuf / lgbuf are next written after several barriers of the next sample
+        WN_TMARK(10)
     }
+#ifdef WN_TIMING
+    if (tid == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 12; i++) p.p[i] = (float)tacc[i];
+#endif
 
     if (w == 0 && g == 0) {
 #pragma unroll
