@@ -112,19 +112,29 @@ protected:
         gpuErrChk(hipGetLastError());
         gpuErrChk(hipStreamSynchronize(0));
     }
-    template <int BT> bool launch(const wn::Params& p, int tiles, hipStream_t stream) {
+    template <int BT> static size_t ldsNeed(int L, bool emb) { return wn::Cfg<F16, R, S, A, BT>::ldsBytes(L, emb); }
+    static constexpr size_t kLdsMax = 160 * 1024;
+    template <int BT> bool ldsFits() const { return ldsNeed<BT>(m_numLayers, false) <= kLdsMax; }
+    template <int BT> bool embFits() const { return ldsNeed<BT>(m_numLayers, true) <= kLdsMax; }
+    template <int BT, bool EMB> bool launchK(const wn::Params& p, int tiles, hipStream_t stream) {
         using CB = wn::Cfg<F16, R, S, A, BT>;
         const int grid = (tiles + BT - 1) / BT;
-        hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT>), dim3(grid), dim3(CB::THREADS),
-                           CB::ldsBytes(m_numLayers), stream, p);
+        hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB>), dim3(grid), dim3(CB::THREADS),
+                           ldsNeed<BT>(m_numLayers, EMB), stream, p);
         return hipGetLastError() == hipSuccess;
     }
-    template <int BT> bool ldsFits() const { return wn::Cfg<F16, R, S, A, BT>::ldsBytes(m_numLayers) <= 160 * 1024; }
+    template <int BT> bool launch(const wn::Params& p, int tiles, hipStream_t stream) {
+        return embFits<BT>() ? launchK<BT, true>(p, tiles, stream) : launchK<BT, false>(p, tiles, stream);
+    }
+    template <int BT, bool EMB> void allowLdsK() {
+        const size_t need = ldsNeed<BT>(m_numLayers, EMB);
+        if (need <= kLdsMax)
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    }
     template <int BT> void allowLds() {
-        if (ldsFits<BT>())
-            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)wn::Cfg<F16, R, S, A, BT>::ldsBytes(m_numLayers)));
+        allowLdsK<BT, false>();
+        allowLdsK<BT, true>();
     }
     float* headBias() { return m_bias + (size_t)m_numLayers * C::BIAS_L; }
 
@@ -134,7 +144,7 @@ public:
         : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
           m_num_samples_per_chunk(0), m_stage(NULL), m_stageElems(0) {
-        assert(numLayers > 0 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
+        assert(numLayers >= 2 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
         m_tiles = ((batchSize + 15) / 16 + MAXBT - 1) / MAXBT * MAXBT;   // whole workgroups of MAXBT tiles
         {
             int dev = 0;
@@ -199,7 +209,7 @@ public:
 
         if (!ldsFits<1>()) {
             fprintf(stderr, "nvWavenetInfer: R=%d S=%d A=%d with %d layers needs %zu bytes of LDS (> 160 KiB)\n", R, S,
-                    A, numLayers, wn::Cfg<F16, R, S, A, 1>::ldsBytes(numLayers));
+                    A, numLayers, ldsNeed<1>(numLayers, false));
             exit(1);
         }
         allowLds<1>();
@@ -249,7 +259,7 @@ public:
     }
     // col-major Wzs AxS, Bzs A, Wza AxA, Bza A (nv_wavenet.cuh:410-415)
     virtual void setOutWeights(float* Wzs, float* Bzs, float* Wza, float* Bza) {
-        const size_t hf = (size_t)m_numLayers * C::FLW;
+        const size_t hf = C::headOffsetFrags(m_numLayers);
         packWeight(hf, Wzs, A, S, 0);
         packWeight(hf + C::FW_ZS, Wza, A, A, 0);
         gpuErrChk(hipMemcpy(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault));
@@ -390,13 +400,17 @@ public:
         p.tiles = m_tiles;
         p.tanhEmbed = m_tanhEmbed ? 1 : 0;
         p.dump = dumpActivations ? 1 : 0;
+        // rings + conditioning of many tiles stream through HBM: keep them from evicting the weights
+        p.ntStream = ((size_t)((batch_size + 15) / 16) * m_ringSlots * R * 16 * sizeof(elem) > ((size_t)16 << 20)) ? 1 : 0;
         if (p.count <= 0) return true;
 
         // one tile of 16 utterances per workgroup while the CUs are not all busy (lowest latency);
         // two tiles per workgroup share one pass over the weights beyond that
         const int tiles = (batch_size + 15) / 16;
         bool result;
-        if (tiles > m_numCUs && ldsFits<2>()) result = launch<2>(p, tiles, stream);
+        const char* forceBt = getenv("NVW_FORCE_BT");   // experiments only
+        const bool two = forceBt ? (atoi(forceBt) == 2) : (tiles > m_numCUs);
+        if (two && ldsFits<2>()) result = launch<2>(p, tiles, stream);
         else result = launch<1>(p, tiles, stream);
         if (yOut != NULL) {
             gpuErrChk(hipMemcpyAsync(yOut, m_yOut, (size_t)m_maxSamples * m_maxBatch * sizeof(int), hipMemcpyDefault,

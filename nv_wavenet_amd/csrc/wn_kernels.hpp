@@ -48,6 +48,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace wn {
 
 #define WN_DEV __device__ __forceinline__
@@ -98,8 +100,14 @@ struct Cfg {
     // per-wave fragment stream of the head: zs | za
     static constexpr int FW_ZS = ATW * KF_S, FW_ZA = ATW * KF_A;
     static constexpr int FHW = FW_ZS + FW_ZA;
-    static constexpr int PF = pick_pf(FLW, 24);
+    // depth of the per-wave weight prefetch ring.  Deeper is NOT better: measured on MI355X, 18 in
+    // flight per wave is 12% slower than 9 (the wave's VMEM queue fills and instruction issue stalls).
+    static constexpr int PF = pick_pf(FLW, 12);
     static_assert(FLW % PF == 0 && PF <= FHW, "prefetch ring must divide the layer stream");
+    // The head's weights (FHW fragments per wave) stay RESIDENT in registers for the whole launch
+    // when they fit the otherwise idle accumulator half of the register file (4 regs/fragment):
+    // the head then needs no weight stream at all (it is purely stream-bound otherwise).
+    static constexpr bool HEADRES = F16 && (FHW * 4 <= 256) && (BT == 1 || FHW * 4 <= 192);
     static constexpr int FRAG_ELEMS = 64 * EPL;
     static constexpr int BIAS_L = 3 * R + S;               // fp32 biases per layer: Bh | Bres | Bskip
     static constexpr int COND_FR = 2 * HTW / TPF;          // conditioning fragments per (sample,layer,tile,wave)
@@ -116,7 +124,13 @@ struct Cfg {
     static constexpr int YBUF = align16(BT * 16 * 4);
     static constexpr int OFF_X = 0, OFF_H = OFF_X + XBUF, OFF_SK = OFF_H + HBUF, OFF_ZS = OFF_SK + SKBUF;
     static constexpr int OFF_LG = OFF_ZS + ZSBUF, OFF_Y = OFF_LG + LGBUF, LDS_FIXED = OFF_Y + YBUF;
-    static size_t ldsBytes(int L) { return (size_t)LDS_FIXED + ((size_t)L * BIAS_L + 2 * A) * sizeof(float); }
+    // + optionally both embedding tables (T_data) behind the bias table
+    static size_t ldsBytes(int L, bool embLds) {
+        return (size_t)LDS_FIXED + ((size_t)L * BIAS_L + 2 * A) * sizeof(float) +
+               (embLds ? (size_t)2 * A * R * sizeof(typename P::elem) : 0);
+    }
+    // per-wave stream in memory: [L][FLW] layers | [FHW] head
+    __host__ __device__ static size_t headOffsetFrags(int L) { return (size_t)L * FLW; }
     __host__ __device__ static size_t waveStreamFrags(int L) { return (size_t)L * FLW + FHW; }
 };
 
@@ -124,7 +138,7 @@ constexpr int kMaxLayers = 128;
 
 // Everything the kernel needs, passed by value (role of nv_wavenet_params, nv_wavenet.cuh:40-85).
 struct Params {
-    const void* wblob;       // NW per-wave streams: [L][FLW] layer fragments then [FHW] head fragments
+    const void* wblob;       // NW per-wave streams: [L][FLW] layer fragments | [FHW] head fragments
     const float* bias;       // [L][BIAS_L] then Bzs[A], Bza[A]
     const void* embPrev;     // [A][R] T_data
     const void* embCur;      // [A][R] T_data
@@ -152,6 +166,7 @@ struct Params {
     int tiles;               // ceil(maxBatch/16): tile stride of cond / ring
     int tanhEmbed;
     int dump;
+    int ntStream;            // non-temporal ring / conditioning traffic (large batches)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -217,6 +232,16 @@ WN_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: 
 WN_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
 
+// Streaming (non-temporal) access for data that is touched once per sample (conditioning) or
+// re-read only d samples later (dilation ring): keeps it from evicting the weight stream, which
+// every CU of an XCD re-reads from L2 each sample.
+// `nt` is wave-uniform: set by the host when the rings of all tiles cannot stay in L2 anyway.
+template <typename T> WN_DEV T ld_stream(const T* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+template <typename T> WN_DEV void st_stream(T* p, T v, bool nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // ---- LDS exchange of activations as B fragments -------------------------------------------
 // tile t of a vector, held in MFMA D layout (fp32), goes to its place in the fragment image
 template <bool F16> WN_DEV void lds_put_tile(char* buf, int tile, int lane, floatx4 v);
@@ -240,44 +265,64 @@ template <bool F16, int PF> struct WStream {
     typename Prec<F16>::frag buf[PF];
 };
 
-// Consume fragment `idx` (position inside the current body, a compile-time constant after
-// unrolling) and refill its ring slot with fragment idx+PF: from the current body while that is
-// inside it (BODY fragments long), otherwise from `next` (the body that follows in the stream).
-template <bool F16, int PF, int BODY>
-WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const char* cur, const char* next,
-                                     unsigned laneOff) {
+// Consume fragment `idx` (position relative to `base`, a compile-time constant after unrolling;
+// `base` sits a whole number of layers from the start of the wave's stream, so idx % PF is the ring
+// slot) and refill the slot with fragment idx+PF.  The stream is contiguous across layers and into
+// the head, so the refill address is linear, except at the end of the head (WRAP = its length)
+// where it continues at `wrapBase` (layer 0 of the next sample).
+template <bool F16, int PF, int WRAP>
+WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const char* base, const char* wrapBase,
+                                     unsigned laneOff, int rtWrapAt = 0x7fffffff, long rtWrapDelta = 0) {
     using frag = typename Prec<F16>::frag;
     frag a = ws.buf[idx % PF];
     int nidx = idx + PF;
 #ifndef WN_ABL_NOWEIGHTLOAD
-    // cur / next are wave-uniform (SGPR base), laneOff = lane*16: one SALU add per fragment at most
-    const char* src = (nidx < BODY) ? cur + (size_t)nidx * 1024 : next + (size_t)(nidx - BODY) * 1024;
+    // base / wrapBase are wave-uniform (SGPR base), laneOff = lane*16.  rtWrapAt/rtWrapDelta: a
+    // run-time (uniform) wrap point, used when the stream cycles over the layers only.
+    const char* src = (WRAP > 0 && nidx >= WRAP) ? wrapBase + (size_t)(nidx - WRAP) * 1024 : base + (size_t)nidx * 1024;
+    if (nidx >= rtWrapAt) src += rtWrapDelta;
     ws.buf[idx % PF] = *(const frag*)(src + laneOff);
 #else
-    (void)nidx; (void)cur; (void)next; (void)laneOff;
+    (void)nidx; (void)base; (void)wrapBase; (void)laneOff; (void)rtWrapAt; (void)rtWrapDelta;
 #endif
     return a;
 }
 
 // acc[bt][mt] += W(tile mt) * b[bt]   for MT tiles of this wave, KF k-fragments, BT batch tiles
-template <bool F16, int PF, int BODY, int BT, int MT, int KF>
+template <bool F16, int PF, int WRAP, int BT, int MT, int KF>
 WN_DEV void gemm(WStream<F16, PF>& ws, int pos0, const char* cur, const char* next, unsigned laneOff,
-                 floatx4 (&acc)[BT][MT], const typename Prec<F16>::frag (&b)[BT][KF]) {
+                 floatx4 (&acc)[BT][MT], const typename Prec<F16>::frag (&b)[BT][KF], int rtWrapAt = 0x7fffffff,
+                 long rtWrapDelta = 0) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
         for (int kf = 0; kf < KF; kf++) {
-            auto a = take<F16, PF, BODY>(ws, pos0 + mt * KF + kf, cur, next, laneOff);
+            auto a = take<F16, PF, WRAP>(ws, pos0 + mt * KF + kf, cur, next, laneOff, rtWrapAt, rtWrapDelta);
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) acc[bt][mt] = mma(a, b[bt][kf], acc[bt][mt]);
         }
     }
 }
 
+// same with register-resident weight fragments
+template <bool F16, int BT, int MT, int KF, int NFR>
+WN_DEV void gemm_res(const typename Prec<F16>::frag (&wres)[NFR], int pos0, floatx4 (&acc)[BT][MT],
+                     const typename Prec<F16>::frag (&b)[BT][KF]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int kf = 0; kf < KF; kf++)
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) acc[bt][mt] = mma(wres[pos0 + mt * KF + kf], b[bt][kf], acc[bt][mt]);
+}
+
 // ------------------------------------------------------------------------------------------
 // the engine kernel: one workgroup generates `count` samples for BT tiles of 16 utterances
 // ------------------------------------------------------------------------------------------
-template <bool F16, int R, int S, int A, int BT>
+// EMBLDS: both embedding tables are copied to LDS at launch, so the gather that follows every
+// sample pick (on the critical path) is a ds_read instead of a global load queued behind the
+// in-flight weight prefetch.
+template <bool F16, int R, int S, int A, int BT, bool EMBLDS>
 __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_wg(const Params p) {
     using C = Cfg<F16, R, S, A, BT>;
     using P = Prec<F16>;
@@ -335,11 +380,26 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     }
 
     const unsigned laneOff = (unsigned)lane * 16u;
+    const bool nt = p.ntStream != 0;
     // wave-uniform byte bases (SGPRs); per-lane part is laneOff
     const char* const wbase = (const char*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 1024;
-    const char* const whead = wbase + (size_t)L * FLW * 1024;
-    const elem* const embPrev = (const elem*)p.embPrev;
-    const elem* const embCur = (const elem*)p.embCur;
+    const char* const whead = wbase + C::headOffsetFrags(L) * 1024;
+    const elem* embPrev = (const elem*)p.embPrev;
+    const elem* embCur = (const elem*)p.embCur;
+    if constexpr (EMBLDS) {
+        elem* const embLds = (elem*)(biasLds + L * C::BIAS_L + 2 * A);
+        constexpr int NQ = A * R / 8;   // 16-byte chunks per table (fp16: 8 elems, fp32: 2 x 4 elems)
+        const floatx4* s0 = (const floatx4*)p.embPrev;
+        const floatx4* s1 = (const floatx4*)p.embCur;
+        constexpr int CH = (int)(A * R * sizeof(elem) / 16);
+        (void)NQ;
+        for (int i = tid; i < CH; i += C::THREADS) {
+            ((floatx4*)embLds)[i] = s0[i];
+            ((floatx4*)embLds)[CH + i] = s1[i];
+        }
+        embPrev = embLds;
+        embCur = embLds + A * R;
+    }
 
     int yPrev[BT], yCur[BT];
     floatx4 ep[BT][HTW];      // embedding row of the older tap, known one sample early
@@ -358,32 +418,44 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     for (int i = 0; i < PF; i++) ws.buf[i] = *(const frag*)(wbase + (size_t)i * 1024 + laneOff);
 
     // ---- prefetch of the dilated input + conditioning of (sample tn, layer ln) ----------------
-    frag xpN[BT][KF_R];
-    frag cdN[BT][C::COND_FR];
+    // ---- resident head weights ------------------------------------------------------------------
+    frag hw[C::HEADRES ? FHW : 1];
+    if constexpr (C::HEADRES) {
+#pragma unroll
+        for (int i = 0; i < FHW; i++) hw[i] = *(const frag*)(whead + (size_t)i * 1024 + laneOff);
+    }
+
+    // ---- prefetch of the dilated input + conditioning, TWO layers ahead (HBM latency of the
+    //      conditioning stream exceeds half a layer) ---------------------------------------------
+    frag xpA[BT][KF_R], xpB[BT][KF_R];          // next layer / the one after
+    frag cdA[BT][C::COND_FR], cdB[BT][C::COND_FR];
     // per-(sample,layer) strides in bytes; everything here is wave-uniform (SALU)
     const size_t condStride = (size_t)p.tiles * NW * C::COND_FR * 1024;            // one (sample,layer) row
     const char* const condMine = (const char*)p.cond + ((size_t)tile0 * NW + w) * C::COND_FR * 1024;
     const size_t ringTile = (size_t)p.ringSlots * KF_R * 1024;
     char* const ringMine = (char*)p.ring + (size_t)tile0 * ringTile;
-    auto prefetch = [&](int tn, int ln) {
+    // loads (sample tn, layer ln) into (xd, cdd); ln may run past L-1 into the next sample.
+    // The conditioning buffer carries one padding sample, so (tEnd, 0..1) stays in bounds.
+    auto prefetch = [&](int tn, int ln, frag (&xd)[BT][KF_R], frag (&cdd)[BT][C::COND_FR]) {
 #ifdef WN_ABL_NOPREFETCH
-        if (tn != p.initSample || ln != 0) return;
+        if (tn != p.initSample || ln > 1) return;
 #endif
+        if (ln >= L) { ln -= L; tn += 1; }
         const int dn = p.dil[ln];
         const unsigned slot = (unsigned)(p.ringOff[ln] + (tn & (dn - 1)));
         const char* rp0 = ringMine + (size_t)slot * (KF_R * 1024);
-        // the conditioning buffer carries one padding sample, so (t+1, 0) is always in bounds
         const char* cp0 = condMine + ((size_t)tn * L + ln) * condStride;
 #pragma unroll
         for (int bt = 0; bt < BT; bt++) {
 #pragma unroll
-            for (int k = 0; k < KF_R; k++) xpN[bt][k] = *(const frag*)(rp0 + bt * ringTile + k * 1024 + laneOff);
+            for (int k = 0; k < KF_R; k++) xd[bt][k] = ld_stream((const frag*)(rp0 + bt * ringTile + k * 1024 + laneOff), nt);
 #pragma unroll
             for (int k = 0; k < C::COND_FR; k++)
-                cdN[bt][k] = *(const frag*)(cp0 + (size_t)bt * NW * C::COND_FR * 1024 + k * 1024 + laneOff);
+                cdd[bt][k] = ld_stream((const frag*)(cp0 + (size_t)bt * NW * C::COND_FR * 1024 + k * 1024 + laneOff), nt);
         }
     };
-    prefetch(p.initSample, 0);
+    prefetch(p.initSample, 0, xpA, cdA);
+    prefetch(p.initSample, 1, xpB, cdB);
 
     __syncthreads();   // bias table visible
 
@@ -445,49 +517,83 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             for (int i = 0; i < STW; i++) skip[bt][i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
         // ---- L dilated layers (nv_wavenet_reference.cpp:58-92) -------------------------------
-        for (int l = 0; l < L; l++) {
-            const char* wl = wbase + (size_t)l * FLW * 1024;
-            const char* wn = wl + (size_t)FLW * 1024;   // next layer, or the head after the last
+        // Schedule of one layer for a wave (critical path: x exchange -> cur GEMM -> gate -> h
+        // exchange -> res GEMM -> x exchange).  The skip GEMM of layer l-1 and the dilated-tap
+        // GEMM of layer l do not depend on x_l, so they are issued first and run while the x
+        // fragments come back from LDS; the weight stream order [prev|cur|res|skip] per layer is
+        // consumed as  prev(0) cur(0) res(0) | skip(0) prev(1) cur(1) res(1) | ... | skip(L-1).
+        frag hb[BT][KF_R];
+        auto layer = [&](auto withSkip, const int l) {
+            constexpr bool SKIP = decltype(withSkip)::value;
+            // fragment positions are relative to the start of layer l-1 (SKIP) / layer l
+            const char* wl = wbase + (size_t)(SKIP ? l - 1 : l) * FLW * 1024;
+            constexpr int OFS = SKIP ? FLW : 0;
+            // with resident head weights the stream cycles over the layers only: prefetches that
+            // run past the last layer continue at layer 0
+            const int wrapAt = C::HEADRES ? (L - (SKIP ? l - 1 : l)) * FLW : 0x7fffffff;
+            const long wrapDelta = C::HEADRES ? -(long)L * FLW * 1024 : 0;
             const float* bl = biasLds + l * C::BIAS_L;
             const int d = p.dil[l];
             const bool havePrev = t >= d;
 
-            // full x as B fragments; x_l[t] replaces x_l[t-d] in the ring (same slot)
+            // x as B fragments (LDS), accumulators start at the gate bias
             frag xb[BT][KF_R];
-            frag xp[BT][KF_R];
-            frag cd[BT][C::COND_FR];
+            floatx4 acc[BT][2 * HTW];
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) {
                 lds_get_frags<F16, KF_R>(xbuf + bt * KF_R * 1024, lane, xb[bt]);
-#pragma unroll
-                for (int k = 0; k < KF_R; k++) {
-                    xp[bt][k] = xpN[bt][k];
-                    if (!havePrev) {
-#pragma unroll
-                        for (int e = 0; e < P::EPL; e++) xp[bt][k][e] = (elem)0.f;   // reference :287
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < C::COND_FR; k++) cd[bt][k] = cdN[bt][k];
-                char* rp = ringMine + bt * ringTile + (size_t)(unsigned)(p.ringOff[l] + (t & (d - 1))) * (KF_R * 1024);
-#pragma unroll
-                for (int k = 0; k < KF_R; k++)
-                    if (k % NW == w) *(frag*)(rp + k * 1024 + laneOff) = xb[bt][k];
-            }
-
-            // z = Wprev x[t-d] + Wcur x[t] + Bh + Lh for this wave's gate pairs:
-            // acc[2i] = tanh rows of tile w+NW*i, acc[2i+1] = sigmoid rows (tile + RT)
-            floatx4 acc[BT][2 * HTW];
-#pragma unroll
-            for (int bt = 0; bt < BT; bt++)
 #pragma unroll
                 for (int i = 0; i < HTW; i++) {
                     acc[bt][2 * i] = *(const floatx4*)(bl + (w + NW * i) * 16 + g * 4);
                     acc[bt][2 * i + 1] = *(const floatx4*)(bl + (w + NW * i + RT) * 16 + g * 4);
                 }
+            }
+            // deferred skip GEMM of the previous layer: skip <- Wskip h + skip
+            if constexpr (SKIP) {
+                gemm<F16, PF, 0, BT, STW, KF_R>(ws, C::O_SKIP, wl, wl, laneOff, skip, hb, wrapAt, wrapDelta);
+                if (dumpNow) {
+                    const float* bp = biasLds + (l - 1) * C::BIAS_L + 3 * R;   // running bias sum
+#pragma unroll
+                    for (int bt = 0; bt < BT; bt++) {
+                        if (!uvalid[bt]) continue;
+#pragma unroll
+                        for (int i = 0; i < STW; i++)
+                            *(floatx4*)(p.skipOut + ((size_t)(l - 1) * p.maxBatch + ub[bt]) * S + (w + NW * i) * 16 + g * 4) =
+                                skip[bt][i] + *(const floatx4*)(bp + (w + NW * i) * 16 + g * 4);
+                    }
+                }
+            }
+            // dilated tap: x_l[t-d] was prefetched; zero before the start (reference :287)
+            frag xp[BT][KF_R];
+            frag cd[BT][C::COND_FR];
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) {
+#pragma unroll
+                for (int k = 0; k < KF_R; k++) {
+                    xp[bt][k] = xpA[bt][k];
+                    if (!havePrev) {
+#pragma unroll
+                        for (int e = 0; e < P::EPL; e++) xp[bt][k][e] = (elem)0.f;
+                    }
+                    xpA[bt][k] = xpB[bt][k];
+                }
+#pragma unroll
+                for (int k = 0; k < C::COND_FR; k++) {
+                    cd[bt][k] = cdA[bt][k];
+                    cdA[bt][k] = cdB[bt][k];
+                }
+            }
             WN_TMARK(1)
-            gemm<F16, PF, FLW, BT, 2 * HTW, KF_R>(ws, C::O_PREV, wl, wn, laneOff, acc, xp);
-            gemm<F16, PF, FLW, BT, 2 * HTW, KF_R>(ws, C::O_CUR, wl, wn, laneOff, acc, xb);
+            gemm<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, OFS + C::O_PREV, wl, wl, laneOff, acc, xp, wrapAt, wrapDelta);
+            // x_l[t] replaces x_l[t-d] in the ring (same slot), then the current tap
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) {
+                char* rp = ringMine + bt * ringTile + (size_t)(unsigned)(p.ringOff[l] + (t & (d - 1))) * (KF_R * 1024);
+#pragma unroll
+                for (int k = 0; k < KF_R; k++)
+                    if (k % NW == w) st_stream((frag*)(rp + k * 1024 + laneOff), xb[bt][k], nt);
+            }
+            gemm<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, OFS + C::O_CUR, wl, wl, laneOff, acc, xb, wrapAt, wrapDelta);
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
@@ -506,28 +612,25 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         hv[r] = tanh_t<F16>(acc[bt][2 * i][r]) * sigmoid_f(acc[bt][2 * i + 1][r]);
                     lds_put_tile<F16>(hbuf + bt * KF_R * 1024, w + NW * i, lane, hv);
                 }
-
             WN_TMARK(2)
-            // prefetch the next layer's dilated input and conditioning (next sample's layer 0
-            // after the last layer)
-            if (l + 1 < L) prefetch(t, l + 1);
-            else prefetch(t + 1, 0);
-
-            WN_TMARK(3)
             wg_barrier();   // h complete
             WN_TMARK(4)
-            frag hb[BT][KF_R];
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(hbuf + bt * KF_R * 1024, lane, hb[bt]);
 
-            // residual: x <- Wres h + Bres + x  (this wave's tiles) -> LDS
+            // residual accumulators start at Bres + x; the dilated input / conditioning of layer
+            // l+2 are requested while the h fragments come back from LDS
             floatx4 xa[BT][HTW];
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
                 for (int i = 0; i < HTW; i++)
                     xa[bt][i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[bt][i];
-            gemm<F16, PF, FLW, BT, HTW, KF_R>(ws, C::O_RES, wl, wn, laneOff, xa, hb);
+            prefetch(t, l + 2, xpB, cdB);
+            WN_TMARK(3)
+
+            // residual: x <- Wres h + Bres + x  (this wave's tiles) -> LDS
+            gemm<F16, PF, 0, BT, HTW, KF_R>(ws, OFS + C::O_RES, wl, wl, laneOff, xa, hb, wrapAt, wrapDelta);
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
@@ -535,34 +638,25 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     x[bt][i] = xa[bt][i];
                     lds_put_tile<F16>(xbuf + bt * KF_R * 1024, w + NW * i, lane, xa[bt][i]);
                 }
-
             WN_TMARK(5)
-            // skip: skip <- Wskip h + skip + Bskip (this wave's tiles); overlaps the x exchange
-            gemm<F16, PF, FLW, BT, STW, KF_R>(ws, C::O_SKIP, wl, wn, laneOff, skip, hb);
-
             if (dumpNow) {
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++) {
                     if (!uvalid[bt]) continue;
-                    const size_t bo = (size_t)l * p.maxBatch + ub[bt];
 #pragma unroll
                     for (int i = 0; i < HTW; i++)
-                        *(floatx4*)(p.xtOut + bo * R + (w + NW * i) * 16 + g * 4) = x[bt][i];
-#pragma unroll
-                    for (int i = 0; i < STW; i++) {
-                        floatx4 v = skip[bt][i] + *(const floatx4*)(bl + 3 * R + (w + NW * i) * 16 + g * 4);
-                        if (l == L - 1) {
-#pragma unroll
-                            for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
-                        }
-                        *(floatx4*)(p.skipOut + bo * S + (w + NW * i) * 16 + g * 4) = v;
-                    }
+                        *(floatx4*)(p.xtOut + ((size_t)l * p.maxBatch + ub[bt]) * R + (w + NW * i) * 16 + g * 4) = x[bt][i];
                 }
             }
             WN_TMARK(6)
             wg_barrier();   // x complete
             WN_TMARK(7)
-        }
+        };
+        layer(std::false_type{}, 0);
+        for (int l = 1; l < L; l++) layer(std::true_type{}, l);
+        // skip GEMM of the last layer
+        gemm<F16, PF, 0, BT, STW, KF_R>(ws, C::O_SKIP, wbase + (size_t)(L - 1) * FLW * 1024, wbase, laneOff, skip, hb,
+                                        C::HEADRES ? FLW : 0x7fffffff, C::HEADRES ? -(long)L * FLW * 1024 : 0);
 
         // ---- output head (nv_wavenet_reference.cpp:94-104) -----------------------------------
 #pragma unroll
@@ -574,6 +668,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
                 lds_put_tile<F16>(skbuf + bt * KF_S * 1024, w + NW * i, lane, v);
+                if (dumpNow && uvalid[bt])   // the oracle applies the ReLU to the last layer's skipOut in place
+                    *(floatx4*)(p.skipOut + ((size_t)(L - 1) * p.maxBatch + ub[bt]) * S + (w + NW * i) * 16 + g * 4) = v;
             }
         wg_barrier();
         floatx4 zs[BT][ATW];
@@ -585,7 +681,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int i = 0; i < ATW; i++) zs[bt][i] = *(const floatx4*)(headBias + (w + NW * i) * 16 + g * 4);
             }
-            gemm<F16, PF, FHW, BT, ATW, KF_S>(ws, 0, whead, wbase, laneOff, zs, sb);
+            if constexpr (C::HEADRES) gemm_res<F16, BT, ATW, KF_S>(hw, 0, zs, sb);
+            else gemm<F16, PF, FHW, BT, ATW, KF_S>(ws, 0, whead, wbase, laneOff, zs, sb);
         }
 #pragma unroll
         for (int bt = 0; bt < BT; bt++)
@@ -608,7 +705,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 for (int i = 0; i < ATW; i++)
                     za[bt][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
             }
-            gemm<F16, PF, FHW, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zb);
+            if constexpr (C::HEADRES) gemm_res<F16, BT, ATW, KF_A>(hw, C::FW_ZS, za, zb);
+            else gemm<F16, PF, FHW, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zb);
             // logits -> LDS [utt][row] (row stride padded by 4 floats: conflict-free b128 writes)
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
@@ -621,7 +719,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         }
         WN_TMARK(8)
         // the head is not a multiple of the ring: rotate the ring back into phase
-        if constexpr (FHW % PF != 0) {
+        if constexpr (!C::HEADRES && FHW % PF != 0) {
             frag tmp[PF];
 #pragma unroll
             for (int i = 0; i < PF; i++) tmp[i] = ws.buf[(i + FHW) % PF];
