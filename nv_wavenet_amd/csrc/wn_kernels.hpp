@@ -107,7 +107,11 @@ struct Cfg {
     // The head's weights (FHW fragments per wave) stay RESIDENT in registers for the whole launch
     // when they fit the otherwise idle accumulator half of the register file (4 regs/fragment):
     // the head then needs no weight stream at all (it is purely stream-bound otherwise).
+#ifdef WN_ABL_NOHEADRES
+    static constexpr bool HEADRES = false;
+#else
     static constexpr bool HEADRES = F16 && (FHW * 4 <= 256) && (BT == 1 || FHW * 4 <= 192);
+#endif
     static constexpr int FRAG_ELEMS = 64 * EPL;
     static constexpr int BIAS_L = 3 * R + S;               // fp32 biases per layer: Bh | Bres | Bskip
     static constexpr int COND_FR = 2 * HTW / TPF;          // conditioning fragments per (sample,layer,tile,wave)
