@@ -20,11 +20,13 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 #include <vector>
 
 #include "wn_kernels.hpp"
+#include "wn_stream.hpp"
 
 #ifndef gpuErrChk
 #define gpuErrChk(ans) { wnGpuAssert((ans), __FILE__, __LINE__); }
@@ -49,11 +51,14 @@ public:
 
 protected:
     using C = wn::Cfg<F16, R, S, A, 1>;   // stream / layout constants do not depend on BT
-    static constexpr int MAXBT = 2;
+    using SC = wn::SCfg<F16, R, S, A>;     // throughput (loader/consumer) kernel
+    static constexpr int MAXBT = 4;        // tiles are allocated in groups of 4 (one workgroup of the throughput kernel)
     using elem = typename wn::Prec<F16>::elem;
 
     Implementation m_implementation;
     int m_numLayers, m_maxBatch, m_maxSamples, m_maxDilation, m_tiles, m_numCUs;
+    bool m_streamMode;   // true: wn::wavenet_stream (>= 1 tile per SIMD), false: wn::wavenet_wg (lowest latency)
+    int m_streamNS;      // LDS ring slots of the throughput kernel
     bool m_tanhEmbed;
     int m_num_samples_per_chunk;
     int m_ringSlots;
@@ -103,6 +108,14 @@ protected:
         hipLaunchKernelGGL((wn::pack_weight_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0,
                            m_wblob + blockFrag * C::FRAG_ELEMS, d, M, K, C::NW,
                            C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS, gateRT);
+        gpuErrChk(hipGetLastError());
+        gpuErrChk(hipStreamSynchronize(0));
+    }
+    // same for the shared stream of the throughput kernel (fragment offset inside the one stream)
+    void packWeightStream(size_t fragOff, const float* src, int M, int K, int rowperm) {
+        const float* d = onDevice(src, (size_t)M * K);
+        hipLaunchKernelGGL((wn::pack_weight_stream_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0,
+                           m_wblob + fragOff * SC::FRAG_ELEMS, d, M, K, rowperm);
         gpuErrChk(hipGetLastError());
         gpuErrChk(hipStreamSynchronize(0));
     }
@@ -167,7 +180,21 @@ public:
         }
         m_ringSlots = slots;
 
-        const size_t wElems = (size_t)C::NW * C::waveStreamFrags(numLayers) * C::FRAG_ELEMS;
+        // kernel organisation: with more tiles than CUs every SIMD gets its own tile and the weights
+        // are streamed once per CU through an LDS ring (wn_stream.hpp); otherwise one tile is split
+        // over the 4 SIMDs of a CU (wn_kernels.hpp).  NVW_MODE=stream|wg overrides (experiments).
+        {
+            const size_t biasBytes = ((size_t)numLayers * SC::BIAS_L + 2 * A) * sizeof(float);
+            long ns = ((long)kLdsMax - (long)biasBytes) / ((long)SC::CH * 1024);
+            m_streamNS = (int)(ns > 6 ? 6 : ns);
+            const char* mode = getenv("NVW_MODE");
+            m_streamMode = (batchSize + 15) / 16 > m_numCUs;
+            if (mode && !strcmp(mode, "stream")) m_streamMode = true;
+            if (mode && !strcmp(mode, "wg")) m_streamMode = false;
+            if (m_streamNS < SC::MIN_NS) m_streamMode = false;
+        }
+        const size_t wElems = m_streamMode ? SC::streamFrags(numLayers) * SC::FRAG_ELEMS
+                                           : (size_t)C::NW * C::waveStreamFrags(numLayers) * C::FRAG_ELEMS;
         gpuErrChk(hipMalloc(&m_wblob, wElems * sizeof(elem)));
         gpuErrChk(hipMemset(m_wblob, 0, wElems * sizeof(elem)));
         const size_t bElems = (size_t)numLayers * C::BIAS_L + 2 * A;
@@ -214,6 +241,10 @@ public:
         }
         allowLds<1>();
         allowLds<2>();
+        if (m_streamMode)
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_stream<F16, R, S, A>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)SC::ldsBytes(numLayers, m_streamNS)));
         gpuErrChk(hipDeviceSynchronize());
     }
 
@@ -248,10 +279,18 @@ public:
                                  float* Wskip, float* Bskip) {
         assert(layer >= 0 && layer < m_numLayers);
         const size_t lf = (size_t)layer * C::FLW;
-        packWeight(lf + C::O_PREV, Wprev, 2 * R, R, C::RT);
-        packWeight(lf + C::O_CUR, Wcur, 2 * R, R, C::RT);
-        packWeight(lf + C::O_RES, Wres, R, R, 0);
-        packWeight(lf + C::O_SKIP, Wskip, S, R, 0);
+        if (m_streamMode) {
+            const size_t sf = (size_t)layer * SC::FLP;
+            packWeightStream(sf + SC::O_PREV, Wprev, 2 * R, R, 0);
+            packWeightStream(sf + SC::O_CUR, Wcur, 2 * R, R, 0);
+            packWeightStream(sf + SC::O_RES, Wres, R, R, 0);
+            packWeightStream(sf + SC::O_SKIP, Wskip, S, R, 0);
+        } else {
+            packWeight(lf + C::O_PREV, Wprev, 2 * R, R, C::RT);
+            packWeight(lf + C::O_CUR, Wcur, 2 * R, R, C::RT);
+            packWeight(lf + C::O_RES, Wres, R, R, 0);
+            packWeight(lf + C::O_SKIP, Wskip, S, R, 0);
+        }
         float* b = m_bias + (size_t)layer * C::BIAS_L;
         gpuErrChk(hipMemcpy(b, Bh, 2 * R * sizeof(float), hipMemcpyDefault));
         gpuErrChk(hipMemcpy(b + 2 * R, Bres, R * sizeof(float), hipMemcpyDefault));
@@ -260,8 +299,14 @@ public:
     // col-major Wzs AxS, Bzs A, Wza AxA, Bza A (nv_wavenet.cuh:410-415)
     virtual void setOutWeights(float* Wzs, float* Bzs, float* Wza, float* Bza) {
         const size_t hf = C::headOffsetFrags(m_numLayers);
-        packWeight(hf, Wzs, A, S, 0);
-        packWeight(hf + C::FW_ZS, Wza, A, A, 0);
+        if (m_streamMode) {
+            const size_t sh = (size_t)m_numLayers * SC::FLP;
+            packWeightStream(sh, Wzs, A, S, 0);
+            packWeightStream(sh + SC::F_ZS, Wza, A, A, 1);   // lane-contiguous logit rows
+        } else {
+            packWeight(hf, Wzs, A, S, 0);
+            packWeight(hf + C::FW_ZS, Wza, A, A, 0);
+        }
         gpuErrChk(hipMemcpy(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault));
         gpuErrChk(hipMemcpy(headBias() + A, Bza, A * sizeof(float), hipMemcpyDefault));
     }
@@ -281,8 +326,12 @@ public:
         for (size_t r0 = 0; r0 < rows; r0 += chunkRows) {
             const size_t nr = (rows - r0 < chunkRows) ? rows - r0 : chunkRows;
             const float* src = onDevice(Lh + r0 * srcPerRow, nr * srcPerRow);
-            hipLaunchKernelGGL((wn::pack_cond_kernel<F16>), dim3(gridFor(nr * dstPerRow)), dim3(256), 0, 0,
-                               m_cond + r0 * dstPerRow, src, nr, m_maxBatch, m_tiles, R, C::NW);
+            if (m_streamMode)
+                hipLaunchKernelGGL((wn::pack_cond_stream_kernel<F16>), dim3(gridFor(nr * dstPerRow)), dim3(256), 0, 0,
+                                   m_cond + r0 * dstPerRow, src, nr, m_maxBatch, m_tiles, 2 * R);
+            else
+                hipLaunchKernelGGL((wn::pack_cond_kernel<F16>), dim3(gridFor(nr * dstPerRow)), dim3(256), 0, 0,
+                                   m_cond + r0 * dstPerRow, src, nr, m_maxBatch, m_tiles, R, C::NW);
             gpuErrChk(hipGetLastError());
             gpuErrChk(hipStreamSynchronize(0));
         }
@@ -410,7 +459,11 @@ public:
         bool result;
         const char* forceBt = getenv("NVW_FORCE_BT");   // experiments only
         const bool two = forceBt ? (atoi(forceBt) == 2) : (tiles > m_numCUs);
-        if (two && ldsFits<2>()) result = launch<2>(p, tiles, stream);
+        if (m_streamMode) {
+            hipLaunchKernelGGL((wn::wavenet_stream<F16, R, S, A>), dim3((tiles + 3) / 4), dim3(512),
+                               SC::ldsBytes(m_numLayers, m_streamNS), stream, p, m_streamNS);
+            result = hipGetLastError() == hipSuccess;
+        } else if (two && ldsFits<2>()) result = launch<2>(p, tiles, stream);
         else result = launch<1>(p, tiles, stream);
         if (yOut != NULL) {
             gpuErrChk(hipMemcpyAsync(yOut, m_yOut, (size_t)m_maxSamples * m_maxBatch * sizeof(int), hipMemcpyDefault,

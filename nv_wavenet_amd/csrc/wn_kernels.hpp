@@ -297,13 +297,20 @@ template <bool F16, int PF, int WRAP, int BT, int MT, int KF>
 WN_DEV void gemm(WStream<F16, PF>& ws, int pos0, const char* cur, const char* next, unsigned laneOff,
                  floatx4 (&acc)[BT][MT], const typename Prec<F16>::frag (&b)[BT][KF], int rtWrapAt = 0x7fffffff,
                  long rtWrapDelta = 0) {
+    // fragment order inside a GEMM: groups of G tile slots, k-fragment-major inside a group, so that
+    // MFMAs accumulating into the same tile are G instructions apart (no dependent-MFMA stall)
+    constexpr int G = MT >= 4 ? 4 : MT;
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
+    for (int mg = 0; mg < MT / G; mg++) {
 #pragma unroll
         for (int kf = 0; kf < KF; kf++) {
-            auto a = take<F16, PF, WRAP>(ws, pos0 + mt * KF + kf, cur, next, laneOff, rtWrapAt, rtWrapDelta);
 #pragma unroll
-            for (int bt = 0; bt < BT; bt++) acc[bt][mt] = mma(a, b[bt][kf], acc[bt][mt]);
+            for (int mi = 0; mi < G; mi++) {
+                const int mt = mg * G + mi;
+                auto a = take<F16, PF, WRAP>(ws, pos0 + (mg * KF + kf) * G + mi, cur, next, laneOff, rtWrapAt, rtWrapDelta);
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++) acc[bt][mt] = mma(a, b[bt][kf], acc[bt][mt]);
+            }
         }
     }
 }
@@ -312,12 +319,16 @@ WN_DEV void gemm(WStream<F16, PF>& ws, int pos0, const char* cur, const char* ne
 template <bool F16, int BT, int MT, int KF, int NFR>
 WN_DEV void gemm_res(const typename Prec<F16>::frag (&wres)[NFR], int pos0, floatx4 (&acc)[BT][MT],
                      const typename Prec<F16>::frag (&b)[BT][KF]) {
+    constexpr int G = MT >= 4 ? 4 : MT;
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+    for (int mg = 0; mg < MT / G; mg++)
 #pragma unroll
         for (int kf = 0; kf < KF; kf++)
 #pragma unroll
-            for (int bt = 0; bt < BT; bt++) acc[bt][mt] = mma(wres[pos0 + mt * KF + kf], b[bt][kf], acc[bt][mt]);
+            for (int mi = 0; mi < G; mi++)
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++)
+                    acc[bt][mg * G + mi] = mma(wres[pos0 + (mg * KF + kf) * G + mi], b[bt][kf], acc[bt][mg * G + mi]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -392,17 +403,16 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     const elem* embCur = (const elem*)p.embCur;
     if constexpr (EMBLDS) {
         elem* const embLds = (elem*)(biasLds + L * C::BIAS_L + 2 * A);
-        constexpr int NQ = A * R / 8;   // 16-byte chunks per table (fp16: 8 elems, fp32: 2 x 4 elems)
         const floatx4* s0 = (const floatx4*)p.embPrev;
         const floatx4* s1 = (const floatx4*)p.embCur;
         constexpr int CH = (int)(A * R * sizeof(elem) / 16);
-        (void)NQ;
         for (int i = tid; i < CH; i += C::THREADS) {
             ((floatx4*)embLds)[i] = s0[i];
             ((floatx4*)embLds)[CH + i] = s1[i];
         }
         embPrev = embLds;
         embCur = embLds + A * R;
+        __syncthreads();   // the tables are complete before the first gather below
     }
 
     int yPrev[BT], yCur[BT];
@@ -838,8 +848,11 @@ __global__ void pack_weight_kernel(typename Prec<F16>::elem* __restrict__ dst, c
         size_t r = idx % perWave;
         const int e = r % EPL; r /= EPL;
         const int lane = r % 64; r /= 64;
-        const int kf = r % KF;
-        const int it = r / KF;                         // tile slot inside the wave's list
+        // slot order inside a matrix: groups of G slots, k-fragment-major inside a group (see gemm())
+        const int G = tilesPerWave >= 4 ? 4 : tilesPerWave;
+        const int mi = r % G;
+        const int kf = (r / G) % KF;
+        const int it = (r / (G * KF)) * G + mi;        // tile slot inside the wave's list
         int tile;
         if (gateRT > 0) tile = w + NW * (it >> 1) + (it & 1) * gateRT;
         else tile = w + NW * it;
