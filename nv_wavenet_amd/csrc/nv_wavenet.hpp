@@ -428,7 +428,7 @@ public:
         p.cond = m_cond;
         p.sel = m_outputSelectors;
         p.ring = m_ring;
-        for (int l = 0; l < wn::kMaxLayers; l++) p.dil[l] = m_dil[l], p.ringOff[l] = m_ringOff[l];
+        p.maxDilation = m_maxDilation;
         p.yInPrev = m_yInPrev;
         p.yInCur = m_yInCur;
         p.yOut = m_yOut;

@@ -140,6 +140,21 @@ struct Cfg {
 
 constexpr int kMaxLayers = 128;
 
+// Dilation d_l and first ring slot of layer l, advanced layer by layer with scalar arithmetic
+// (no table loads: a load result needed "now" would wait behind the in-flight weight prefetch).
+struct Dil {
+    int d, off;
+};
+WN_DEV Dil dil_first() { return Dil{1, 0}; }
+WN_DEV Dil dil_next(Dil s, int maxDilation, bool wrapToFirst) {
+    Dil n;
+    n.off = s.off + s.d;
+    n.d = s.d << 1;
+    if (n.d > maxDilation) n.d = 1;
+    if (wrapToFirst) n = dil_first();
+    return n;
+}
+
 // Everything the kernel needs, passed by value (role of nv_wavenet_params, nv_wavenet.cuh:40-85).
 struct Params {
     const void* wblob;       // NW per-wave streams: [L][FLW] layer fragments | [FHW] head fragments
@@ -149,8 +164,7 @@ struct Params {
     const void* cond;        // [sample][L][tile][wave][COND_FR] fragments
     const float* sel;        // [N][maxBatch] uniform draws
     void* ring;              // [tile][ringSlots][KF_R] fragments
-    int dil[kMaxLayers];     // dilation of layer l       (by value: read with scalar loads, so a
-    int ringOff[kMaxLayers]; // first ring slot of layer l  use never waits on the weight stream)
+    int maxDilation;         // dilation doubles per layer and restarts at 1 past this (nv_wavenet.cuh:110-111)
     int* yInPrev;            // [maxBatch]
     int* yInCur;             // [maxBatch]
     int* yOut;               // [batch][numSamples]
@@ -213,6 +227,51 @@ WN_DEV float tanh_acc(float x) {
 template <bool F16> WN_DEV float tanh_t(float x) { return F16 ? tanh_fast(x) : tanh_acc(x); }
 #else
 template <bool F16> WN_DEV float tanh_t(float x) { return x; }
+#endif
+
+// ---- the gate  h = tanh(a) * sigmoid(b)  on 4 values -------------------------------------------
+// fp32 engine: the accurate scalar forms above (parity bars are relative, nv_wavenet_test.cu:273-298).
+// fp16 engine: exp/rcp forms as well.  (An alternative kept under WN_PADE_GATE evaluates the gate as
+// ONE rational function with a single reciprocal instead of 2 exp + 2 rcp per value; measured on
+// MI355X it is SLOWER -- 1770 vs 1470 clk per layer in wavenet_stream -- the transcendental pipe is
+// not the bottleneck, the extra packed FMAs are:
+//   tanh(x) ~ N(x)/D(x), the (7,6) Pade approximant, x clamped to +-4.97 (|error| < 1e-4 everywhere);
+//   sigmoid(b) = 0.5 + 0.5 tanh(b/2)  =>  h = Na (Db + Nb) / (2 Da Db).   Max |error| of h: 1.2e-4.
+// Everything but the reciprocal is packed-fp32 FMA work.
+template <bool F16> WN_DEV floatx4 gate4(floatx4 a, floatx4 b);
+template <> WN_DEV floatx4 gate4<false>(floatx4 a, floatx4 b) {
+    floatx4 h;
+#pragma unroll
+    for (int r = 0; r < 4; r++) h[r] = tanh_t<false>(a[r]) * sigmoid_f(b[r]);
+    return h;
+}
+#ifdef WN_ABL_NOACT
+template <> WN_DEV floatx4 gate4<true>(floatx4 a, floatx4 b) { return a * b; }
+#elif defined(WN_PADE_GATE)
+template <> WN_DEV floatx4 gate4<true>(floatx4 a, floatx4 b) {
+    const float CL = 4.97f;
+    a = __builtin_elementwise_min(__builtin_elementwise_max(a, floatx4{-CL, -CL, -CL, -CL}), floatx4{CL, CL, CL, CL});
+    b = b * 0.5f;
+    b = __builtin_elementwise_min(__builtin_elementwise_max(b, floatx4{-CL, -CL, -CL, -CL}), floatx4{CL, CL, CL, CL});
+    const floatx4 a2 = a * a, b2 = b * b;
+    const floatx4 na = a * (135135.f + a2 * (17325.f + a2 * (378.f + a2)));
+    const floatx4 da = 135135.f + a2 * (62370.f + a2 * (3150.f + a2 * 28.f));
+    const floatx4 nb = b * (135135.f + b2 * (17325.f + b2 * (378.f + b2)));
+    const floatx4 db = 135135.f + b2 * (62370.f + b2 * (3150.f + b2 * 28.f));
+    const floatx4 num = na * (db + nb);
+    const floatx4 den = (da * db) * 2.0f;
+    floatx4 h;
+#pragma unroll
+    for (int r = 0; r < 4; r++) h[r] = num[r] * fast_rcp(den[r]);
+    return h;
+}
+#else
+template <> WN_DEV floatx4 gate4<true>(floatx4 a, floatx4 b) {
+    floatx4 h;
+#pragma unroll
+    for (int r = 0; r < 4; r++) h[r] = tanh_t<true>(a[r]) * sigmoid_f(b[r]);
+    return h;
+}
 #endif
 
 WN_DEV floatx4 mma(half8 a, half8 b, floatx4 c) {
@@ -450,13 +509,12 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     char* const ringMine = (char*)p.ring + (size_t)tile0 * ringTile;
     // loads (sample tn, layer ln) into (xd, cdd); ln may run past L-1 into the next sample.
     // The conditioning buffer carries one padding sample, so (tEnd, 0..1) stays in bounds.
-    auto prefetch = [&](int tn, int ln, frag (&xd)[BT][KF_R], frag (&cdd)[BT][C::COND_FR]) {
+    auto prefetch = [&](int tn, int ln, Dil dl, frag (&xd)[BT][KF_R], frag (&cdd)[BT][C::COND_FR]) {
 #ifdef WN_ABL_NOPREFETCH
         if (tn != p.initSample || ln > 1) return;
 #endif
         if (ln >= L) { ln -= L; tn += 1; }
-        const int dn = p.dil[ln];
-        const unsigned slot = (unsigned)(p.ringOff[ln] + (tn & (dn - 1)));
+        const unsigned slot = (unsigned)(dl.off + (tn & (dl.d - 1)));
         const char* rp0 = ringMine + (size_t)slot * (KF_R * 1024);
         const char* cp0 = condMine + ((size_t)tn * L + ln) * condStride;
 #pragma unroll
@@ -468,8 +526,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 cdd[bt][k] = ld_stream((const frag*)(cp0 + (size_t)bt * NW * C::COND_FR * 1024 + k * 1024 + laneOff), nt);
         }
     };
-    prefetch(p.initSample, 0, xpA, cdA);
-    prefetch(p.initSample, 1, xpB, cdB);
+    prefetch(p.initSample, 0, dil_first(), xpA, cdA);
+    prefetch(p.initSample, 1, dil_next(dil_first(), p.maxDilation, false), xpB, cdB);
 
     __syncthreads();   // bias table visible
 
@@ -537,7 +595,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         // fragments come back from LDS; the weight stream order [prev|cur|res|skip] per layer is
         // consumed as  prev(0) cur(0) res(0) | skip(0) prev(1) cur(1) res(1) | ... | skip(L-1).
         frag hb[BT][KF_R];
-        auto layer = [&](auto withSkip, const int l) {
+        auto layer = [&](auto withSkip, const int l, const Dil dl, const Dil dl2) {
             constexpr bool SKIP = decltype(withSkip)::value;
             // fragment positions are relative to the start of layer l-1 (SKIP) / layer l
             const char* wl = wbase + (size_t)(SKIP ? l - 1 : l) * FLW * 1024;
@@ -547,7 +605,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             const int wrapAt = C::HEADRES ? (L - (SKIP ? l - 1 : l)) * FLW : 0x7fffffff;
             const long wrapDelta = C::HEADRES ? -(long)L * FLW * 1024 : 0;
             const float* bl = biasLds + l * C::BIAS_L;
-            const int d = p.dil[l];
+            const int d = dl.d;
             const bool havePrev = t >= d;
 
             // x as B fragments (LDS), accumulators start at the gate bias
@@ -602,7 +660,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             // x_l[t] replaces x_l[t-d] in the ring (same slot), then the current tap
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) {
-                char* rp = ringMine + bt * ringTile + (size_t)(unsigned)(p.ringOff[l] + (t & (d - 1))) * (KF_R * 1024);
+                char* rp = ringMine + bt * ringTile + (size_t)(unsigned)(dl.off + (t & (d - 1))) * (KF_R * 1024);
 #pragma unroll
                 for (int k = 0; k < KF_R; k++)
                     if (k % NW == w) st_stream((frag*)(rp + k * 1024 + laneOff), xb[bt][k], nt);
@@ -620,10 +678,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
                 for (int i = 0; i < HTW; i++) {
-                    floatx4 hv;
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        hv[r] = tanh_t<F16>(acc[bt][2 * i][r]) * sigmoid_f(acc[bt][2 * i + 1][r]);
+                    const floatx4 hv = gate4<F16>(acc[bt][2 * i], acc[bt][2 * i + 1]);
                     lds_put_tile<F16>(hbuf + bt * KF_R * 1024, w + NW * i, lane, hv);
                 }
             WN_TMARK(2)
@@ -640,7 +695,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int i = 0; i < HTW; i++)
                     xa[bt][i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[bt][i];
-            prefetch(t, l + 2, xpB, cdB);
+            prefetch(t, l + 2, dl2, xpB, cdB);
             WN_TMARK(3)
 
             // residual: x <- Wres h + Bres + x  (this wave's tiles) -> LDS
@@ -666,8 +721,19 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             wg_barrier();   // x complete
             WN_TMARK(7)
         };
-        layer(std::false_type{}, 0);
-        for (int l = 1; l < L; l++) layer(std::true_type{}, l);
+        {
+            Dil d0 = dil_first();
+            Dil d1 = dil_next(d0, p.maxDilation, 1 >= L);
+            Dil d2 = dil_next(d1, p.maxDilation, 2 >= L && 2 - L == 0);
+            // dK = schedule entry of layer (l+K) mod L, (l+2 may wrap into the next sample)
+            layer(std::false_type{}, 0, d0, d2);
+            for (int l = 1; l < L; l++) {
+                d0 = d1;
+                d1 = d2;
+                d2 = dil_next(d1, p.maxDilation, l + 2 == L);   // layer l+2 == L is layer 0 of the next sample
+                layer(std::true_type{}, l, d0, d2);
+            }
+        }
         // skip GEMM of the last layer
         gemm<F16, PF, 0, BT, STW, KF_R>(ws, C::O_SKIP, wbase + (size_t)(L - 1) * FLW * 1024, wbase, laneOff, skip, hb,
                                         C::HEADRES ? FLW : 0x7fffffff, C::HEADRES ? -(long)L * FLW * 1024 : 0);

@@ -246,10 +246,9 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
 
     // prefetch of the dilated input + conditioning, one layer ahead, issued at the top of a layer
     frag xpN[KF_R], cdN[C::COND_FR];
-    auto prefetch = [&](int tn, int ln) {
+    auto prefetch = [&](int tn, int ln, Dil dl) {
         if (ln >= L) { ln -= L; tn += 1; }
-        const int dn = p.dil[ln];
-        const unsigned sl = (unsigned)(p.ringOff[ln] + (tn & (dn - 1)));
+        const unsigned sl = (unsigned)(dl.off + (tn & (dl.d - 1)));
         const char* rp = ringMine + (size_t)sl * (KF_R * 1024);
         const char* cp = condMine + ((size_t)tn * L + ln) * condStride;     // padded by one sample
 #pragma unroll
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
 #pragma unroll
         for (int k = 0; k < C::COND_FR; k++) cdN[k] = ld_stream((const frag*)(cp + k * 1024 + laneOff), nt);
     };
-    prefetch(p.initSample, 0);
+    prefetch(p.initSample, 0, dil_first());
 
     // barrier #0 (chunks 0 and 1 have landed), then fill the read-ahead ring; from here on the
     // per-chunk barriers inside gemm_s are #1, #2, ...
@@ -267,10 +266,24 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
         ab[i] = *(const frag*)(ringLds + (size_t)rd * 1024 + laneOff);
         rd_advance(1);
     }
+#ifdef WN_TIMING
+    unsigned long long tacc[12] = {0};
+    unsigned long long tmark = __builtin_amdgcn_s_memtime();
+#define WN_SMARK(i)                                                        \
+    {                                                                      \
+        unsigned long long _n = __builtin_amdgcn_s_memtime();              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
+        tacc[i] += _n - tmark;                                             \
+        tmark = _n;                                                        \
+    }
+#else
+#define WN_SMARK(i)
+#endif
     const int tEnd = p.initSample + p.count;
     for (int t = p.initSample; t < tEnd; t++) {
         const bool dumpNow = p.dump && (t == tEnd - 1);
         const float selv = p.sel[(size_t)t * p.maxBatch + bc];
+        WN_SMARK(11)
 
         // ---- embedding (nv_wavenet_reference.cpp:42-56) ---------------------------------------
         floatx4 x[RT];
@@ -288,11 +301,14 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
         floatx4 skip[ST];
 #pragma unroll
         for (int i = 0; i < ST; i++) skip[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        WN_SMARK(0)
 
         // ---- L dilated layers (nv_wavenet_reference.cpp:58-92) -------------------------------
+        Dil dl = dil_first();
         for (int l = 0; l < L; l++) {
             const float* bl = biasLds + l * C::BIAS_L;
-            const int d = p.dil[l];
+            const int d = dl.d;
+            const Dil dl1 = dil_next(dl, p.maxDilation, l + 1 == L);
             const bool havePrev = t >= d;
 
             frag xb[KF_R], xp[KF_R], cd[C::COND_FR];
@@ -309,18 +325,20 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
             for (int k = 0; k < C::COND_FR; k++) cd[k] = cdN[k];
             // x_l[t] replaces x_l[t-d] in the ring (same slot), then request layer l+1's inputs
             {
-                char* rp = ringMine + (size_t)(unsigned)(p.ringOff[l] + (t & (d - 1))) * (KF_R * 1024);
+                char* rp = ringMine + (size_t)(unsigned)(dl.off + (t & (d - 1))) * (KF_R * 1024);
 #pragma unroll
                 for (int k = 0; k < KF_R; k++) st_stream((frag*)(rp + k * 1024 + laneOff), xb[k], nt);
             }
-            prefetch(t, l + 1);
+            prefetch(t, l + 1, dl1);
 
             // z = Wprev x[t-d] + Wcur x[t] + Bh + Lh
             floatx4 acc[R2T];
 #pragma unroll
             for (int i = 0; i < R2T; i++) acc[i] = *(const floatx4*)(bl + i * 16 + g * 4);
+            WN_SMARK(1)
             gemm_s(IC_R2T{}, IC_KFR{}, IC_FL{}, IC_FLP{}, C::O_PREV, acc, xp);
             gemm_s(IC_R2T{}, IC_KFR{}, IC_FL{}, IC_FLP{}, C::O_CUR, acc, xb);
+            WN_SMARK(2)
 #pragma unroll
             for (int k = 0; k < C::COND_FR; k++)
 #pragma unroll
@@ -329,9 +347,7 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
             // gate
             floatx4 h[RT];
 #pragma unroll
-            for (int tt = 0; tt < RT; tt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) h[tt][r] = tanh_t<F16>(acc[tt][r]) * sigmoid_f(acc[tt + RT][r]);
+            for (int tt = 0; tt < RT; tt++) h[tt] = gate4<F16>(acc[tt], acc[tt + RT]);
             frag hb[KF_R];
             to_bfrags<RT>(h, hb);
 
@@ -339,12 +355,15 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
             floatx4 xa[RT];
 #pragma unroll
             for (int tt = 0; tt < RT; tt++) xa[tt] = *(const floatx4*)(bl + 2 * R + tt * 16 + g * 4) + x[tt];
+            WN_SMARK(3)
             gemm_s(IC_RT{}, IC_KFR{}, IC_FL{}, IC_FLP{}, C::O_RES, xa, hb);
 #pragma unroll
             for (int tt = 0; tt < RT; tt++) x[tt] = xa[tt];
 
             // skip: skip <- Wskip h + skip   (biases: running sums, added at the head / in dumps)
+            WN_SMARK(4)
             gemm_s(IC_ST{}, IC_KFR{}, IC_FL{}, IC_FLP{}, C::O_SKIP, skip, hb);
+            WN_SMARK(5)
 
             if (dumpNow && valid) {
 #pragma unroll
@@ -360,8 +379,10 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
                     *(floatx4*)(p.skipOut + ((size_t)l * p.maxBatch + b) * S + i * 16 + g * 4) = v;
                 }
             }
+            dl = dl1;
         }
 
+        WN_SMARK(6)
         // ---- output head (nv_wavenet_reference.cpp:94-104) -----------------------------------
         frag zb[KF_A];
         {
@@ -400,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
             for (int i = 0; i < AT; i++) *(floatx4*)(p.za + (size_t)b * A + g * (A / 4) + i * 4) = za[i];
         }
 
+        WN_SMARK(7)
         // ---- softmax + inverse-CDF pick, 4 lanes per utterance (softmax.cuh:36-191; oracle
         //      matrix.cpp:166-183, nv_wavenet_reference.cpp:106-121) ---------------------------
         float m = za[0][0];
@@ -450,7 +472,12 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
         if (valid && g == 0) p.yOut[(size_t)b * p.numSamples + t] = y;
         yPrev = yCur;
         yCur = y;
+        WN_SMARK(8)
     }
+#ifdef WN_TIMING
+    if (tid == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 12; i++) p.p[i] = (float)tacc[i];
+#endif
 
     if (valid && g == 0) {
         p.yInPrev[b] = yPrev;
