@@ -85,10 +85,20 @@ def samples_per_step_for(B):
     return n
 
 
-def measure_khz(w, B, N, seed=11):
-    """per-utterance kHz of one launch at batch B (HIP events on the launch stream)."""
+def measure_khz(w, B, N, seed=11, mode=None):
+    """per-utterance kHz of one launch at batch B (HIP events on the launch stream).
+    mode: None = the engine's own choice; "wg" / "stream" force a kernel organisation."""
     import torch
-    e = build_engine(w, B, N)
+    old = os.environ.get("NVW_MODE")
+    if mode:
+        os.environ["NVW_MODE"] = mode
+    try:
+        e = build_engine(w, B, N)
+    finally:
+        if mode:
+            os.environ.pop("NVW_MODE", None)
+            if old is not None:
+                os.environ["NVW_MODE"] = old
     Lh, sel = device_inputs(B, N, seed)
     e.setInputs(Lh, sel)
     del Lh
@@ -171,7 +181,7 @@ def main():
             c3_b16_khz = measure_khz(w, 16, 1024)
             sweep[16] = c3_b16_khz
             best = 16
-            for tiles_per_cu in (1, 2, 3, 4):
+            for tiles_per_cu in (1, 2, 4):
                 cand = 16 * ncu * tiles_per_cu
                 khz = measure_khz(w, cand, 128)
                 sweep[cand] = khz
@@ -184,6 +194,14 @@ def main():
             dist.broadcast(choice, 0)
         B = int(choice.item())
     N = args.samples or samples_per_step_for(B)
+
+    # throughput mode (not real time): every SIMD owns a tile, weights streamed once per CU
+    thr = None
+    if rank == 0 and not args.batch:
+        bt = 64 * ncu
+        khz_t = sweep.get(bt) or measure_khz(w, bt, 128, mode="stream")
+        thr = {"batch_per_gpu": bt, "khz_per_utterance": khz_t, "samples_per_sec_per_gpu": bt * khz_t * 1e3,
+               "kernel": "wn::wavenet_stream", "real_time": bool(khz_t >= REALTIME_KHZ)}
 
     e = build_engine(w, B, N)
     Lh, sel = device_inputs(B, N, 100 + rank)
@@ -244,7 +262,9 @@ def main():
         units = B * N                                   # utterance-samples per launch
         flops = units * FLOPS
         tiles = (B + 15) // 16
-        passes = (tiles + 1) // 2 if tiles > ncu else tiles     # workgroups (weight-stream passes) per sample
+        stream_mode = tiles > ncu                               # engine's choice (nv_wavenet.hpp)
+        passes = (tiles + 3) // 4 if stream_mode else tiles     # workgroups (weight-stream passes) per sample
+        kname = "wn::wavenet_stream<fp16,64,256,256>" if stream_mode else "wn::wavenet_wg<fp16,64,256,256,BT=1>"
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tf):
@@ -255,7 +275,7 @@ def main():
             except Exception:
                 traffic = None
         roofline = dict(bound="mfma", achieved=flops / (kern_ms * 1e-3) / 1e12, peak=MFMA_F16_PEAK_TFLOPS,
-                        unit="TFLOP/s", traffic=traffic, kernel="wn::wavenet_wg<fp16,64,256,256>",
+                        unit="TFLOP/s", traffic=traffic, kernel=kname,
                         kernel_ms=kern_ms,
                         hbm=dict(achieved=units * HBM_BYTES / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"),
                         l2_weight_stream=dict(achieved=passes * N * WEIGHT_BYTES / (kern_ms * 1e-3) / 1e9,
@@ -275,6 +295,7 @@ def main():
             "khz_per_utterance": khz, "max_realtime_batch_per_gpu": B if khz >= REALTIME_KHZ else None,
             "realtime_sweep_khz": {str(k): v for k, v in sweep.items()},
             "c3_b16": {"khz_per_utterance": c3_b16_khz, "samples_per_sec": None if c3_b16_khz is None else 16e3 * c3_b16_khz},
+            "throughput_mode": thr,
             "distinct_samples_in_last_step": hist,
             "roofline": roofline,
         }

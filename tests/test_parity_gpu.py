@@ -18,8 +18,12 @@ def _bspb(B):
     return 4 if B % 4 == 0 else 2 if B % 2 == 0 else 1  # nv_wavenet_test.cu:247
 
 
+MODES = ["wg", "stream"]   # the two kernel organisations (wn_kernels.hpp / wn_stream.hpp)
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", [c for c in cases.REF_CASES if c.shape.A <= 512], ids=lambda c: c.name)
-def test_reference_harness_fp32(case):
+def test_reference_harness_fp32(case, mode):
     """Re-creation of runTest<float,float,R,S,A> (nv_wavenet_test.cu:44-329): 2 iterations from one
     setInputs, run_chunks(7, ...) so a 7+1 split and an init_sample != 0 relaunch are exercised."""
     s = case.shape
@@ -27,7 +31,7 @@ def test_reference_harness_fp32(case):
     t = util.gen_inputs(case)
     o = util.make_oracle(case, t)
     # pointer permutations like nv_wavenet_test.cu:359-365: odd cases upload from device memory
-    e = util.make_engine(case, t, precision=32, device_ptrs=(case.impl % 2 == 0))
+    e = util.make_engine(case, t, precision=32, device_ptrs=(case.impl % 2 == 0), mode=mode)
     for it in range(case.iters):
         y_ref = o.run(s.N)
         y = np.full((s.B, s.N), -1, dtype=np.int32)
@@ -41,8 +45,9 @@ def test_reference_harness_fp32(case):
     e.close(), o.close()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", cases.EXTRA_CASES, ids=lambda c: c.name)
-def test_baseline_config_shapes_fp32(case):
+def test_baseline_config_shapes_fp32(case, mode):
     """BASELINE.json config shapes over long horizons (ring wrap-around, d up to 512, ragged batch).
     Exact indices expected; a divergence is accepted only when the draw is within 1e-5 of a CDF
     edge of the oracle's pick (then that utterance's later samples legitimately differ)."""
@@ -50,7 +55,7 @@ def test_baseline_config_shapes_fp32(case):
     g = util.load_golden(case.name)
     t = util.gen_inputs(case)
     o = util.make_oracle(case, t)
-    e = util.make_engine(case, t, precision=32)
+    e = util.make_engine(case, t, precision=32, mode=mode)
     y_ref, lo, hi = o.run(s.N, edges=True)
     assert np.array_equal(y_ref, g["yOut"][0])
     y = np.full((s.B, s.N), -1, dtype=np.int32)
@@ -94,8 +99,9 @@ def test_run_equals_run_chunks_and_partial_batch():
     e.close()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["R64S256A256_impl3", "R64S128A256_impl1", "R32S128A256_impl1", "R128S256A256_impl3"])
-def test_fp16_engine_against_fp32_oracle(name):
+def test_fp16_engine_against_fp32_oracle(name, mode):
     """fp16 parity is unpinned by the reference (no test runs half). Stated tolerance: with every
     weight / bias / embedding / conditioning value rounded to fp16 and fed to BOTH sides, the fp16
     engine (fp16 MFMA operands, fp32 accumulation) must give logits within 2e-2*|ref| + 2e-3 of the
@@ -105,7 +111,7 @@ def test_fp16_engine_against_fp32_oracle(name):
     s = case.shape
     t = util.gen_inputs(case, half=True)
     o = util.make_oracle(case, t)
-    e = util.make_engine(case, t, precision=16)
+    e = util.make_engine(case, t, precision=16, mode=mode)
     y_ref = o.run(s.N)
     y = np.full((s.B, s.N), -1, dtype=np.int32)
     assert e.run_chunks(7, None, s.N, s.B, y, 4)

@@ -30,9 +30,26 @@ def make_oracle(case, t):
     return o
 
 
-def make_engine(case, t, precision=32, impl=None, device_ptrs=False):
-    """Build the HIP engine through the C ABI and upload the model + inputs."""
+def make_engine(case, t, precision=32, impl=None, device_ptrs=False, mode=None):
+    """Build the HIP engine through the C ABI and upload the model + inputs.
+    mode: None = the engine's own choice by batch size; "wg" / "stream" force one of the two kernel
+    organisations (NVW_MODE is read by the engine at construction)."""
     from nv_wavenet_amd import WavenetEngine
+    s = case.shape
+    old = os.environ.get("NVW_MODE")
+    if mode is not None:
+        os.environ["NVW_MODE"] = mode
+    try:
+        return _make_engine(WavenetEngine, case, t, precision, impl, device_ptrs)
+    finally:
+        if mode is not None:
+            if old is None:
+                os.environ.pop("NVW_MODE", None)
+            else:
+                os.environ["NVW_MODE"] = old
+
+
+def _make_engine(WavenetEngine, case, t, precision, impl, device_ptrs):
     s = case.shape
     e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, s.B, s.N, impl=case.impl if impl is None else impl,
                       tanhEmbed=True, precision=precision)
