@@ -284,7 +284,10 @@ public:
             packWeightStream(sf + SC::O_PREV, Wprev, 2 * R, R, 0);
             packWeightStream(sf + SC::O_CUR, Wcur, 2 * R, R, 0);
             packWeightStream(sf + SC::O_RES, Wres, R, R, 0);
-            packWeightStream(sf + SC::O_SKIP, Wskip, S, R, 0);
+            // the skip GEMM of layer l is consumed one body later (the head body after the last layer)
+            const size_t skipAt = (layer + 1 < m_numLayers) ? sf + SC::FLP + SC::O_SKIP
+                                                            : (size_t)m_numLayers * SC::FLP + SC::H_SKIP;
+            packWeightStream(skipAt, Wskip, S, R, 0);
         } else {
             packWeight(lf + C::O_PREV, Wprev, 2 * R, R, C::RT);
             packWeight(lf + C::O_CUR, Wcur, 2 * R, R, C::RT);
@@ -301,8 +304,8 @@ public:
         const size_t hf = C::headOffsetFrags(m_numLayers);
         if (m_streamMode) {
             const size_t sh = (size_t)m_numLayers * SC::FLP;
-            packWeightStream(sh, Wzs, A, S, 0);
-            packWeightStream(sh + SC::F_ZS, Wza, A, A, 1);   // lane-contiguous logit rows
+            packWeightStream(sh + SC::H_ZS, Wzs, A, S, 0);
+            packWeightStream(sh + SC::H_ZA, Wza, A, A, 1);   // lane-contiguous logit rows
         } else {
             packWeight(hf, Wzs, A, S, 0);
             packWeight(hf + C::FW_ZS, Wza, A, A, 0);

@@ -22,8 +22,8 @@
 //     LDS-DMA ring delivers 1.73 MB in 11.7 us to all four consumers (scripts/ubench/ldsring.hip).
 //
 // Weight stream (one, shared): [layer 0 .. L-1][head], fragments in consumption order
-//   layer: prev (2R x R) | cur (2R x R) | res (R x R) | skip (S x R), padded to a multiple of 4
-//   head : zs (A x S) | za (A x A, rows permuted so that lane g owns rows g*A/4.. in order)
+//   layer l: prev (2R x R) | cur (2R x R) | skip of layer l-1 (S x R) | res (R x R), padded
+//   head   : skip of layer L-1 | zs (A x S) | za (A x A, rows permuted: lane g owns rows g*A/4..)
 // Conditioning: [sample][layer][tile][fragment] in MFMA D-tile order; ring: [tile][slot][fragment].
 #pragma once
 
@@ -48,13 +48,17 @@ struct SCfg {
     static constexpr int RT = R / 16, R2T = 2 * R / 16, ST = S / 16, AT = A / 16;
     static constexpr int KF_R = RT / TPF, KF_S = ST / TPF, KF_A = AT / TPF;
     static constexpr int F_GATE = R2T * KF_R, F_RES = RT * KF_R, F_SKIP = ST * KF_R;
-    static constexpr int O_PREV = 0, O_CUR = F_GATE, O_RES = 2 * F_GATE, O_SKIP = O_RES + F_RES;
-    static constexpr int FL = O_SKIP + F_SKIP;           // fragments per layer
+    // body of layer l: prev(l) | cur(l) | skip(l-1) | res(l).  The skip GEMM of a layer is consumed one
+    // body later, interleaved with the gate's VALU work (it depends on neither), so the matrix pipe
+    // runs under the transcendental math.  Body 0's skip slot is zeros; skip(L-1) opens the head body.
+    static constexpr int O_PREV = 0, O_CUR = F_GATE, O_SKIP = 2 * F_GATE, O_RES = O_SKIP + F_SKIP;
+    static constexpr int FL = O_RES + F_RES;             // fragments per layer
     static constexpr int FLP = (FL + 7) / 8 * 8;         // padded: splits into chunks of 4k, multiple of the read-ahead
     static constexpr int CH = pick_chunk(FLP, 32);       // fragments per LDS ring chunk
     static constexpr int Q = CH / 4;                     // fragments per loader wave per chunk
     static constexpr int NCH_L = FLP / CH;               // chunks per layer
-    static constexpr int F_ZS = AT * KF_S, F_ZA = AT * KF_A, FH = F_ZS + F_ZA;
+    static constexpr int F_ZS = AT * KF_S, F_ZA = AT * KF_A;
+    static constexpr int H_SKIP = 0, H_ZS = F_SKIP, H_ZA = F_SKIP + F_ZS, FH = H_ZA + F_ZA;   // head body
     static constexpr int FHP = (FH + CH - 1) / CH * CH;
     static constexpr int NCH_H = FHP / CH;
     static constexpr int FRAG_ELEMS = 64 * EPL;
@@ -195,39 +199,39 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
         rd += n;
         if (rd >= ringFrags) rd -= ringFrags;
     };
-    // acc[mt] += W(frag pos0 + mt*KF + kf) * b[kf];  BODY consumed / BODYP stored fragments of the
-    // body this GEMM belongs to (read-ahead skips the padding when it crosses into the next body)
+    // next_frag(f): the A fragment at position f of the current body (BODY consumed / BODYP stored
+    // fragments; read-ahead skips the padding when it crosses into the next body)
+    auto next_frag = [&](auto bodyTag, auto bodypTag, const int f) -> frag {
+        constexpr int BODY = decltype(bodyTag)::value, BODYP = decltype(bodypTag)::value;
+        if (f % CH == 0) {                                         // consumption enters a new chunk
+            if (!firstChunk) asm volatile("s_barrier" ::: "memory");
+            firstChunk = false;
+        }
+        const frag a = ab[f % RA];
+        if (f % RA == 0) {
+            // the next RA read-ahead fragments are contiguous in the ring (everything is kept a
+            // multiple of RA): one address per group, immediates inside it
+            if (f + RA == BODY) rd_advance(BODYP - BODY);          // read-ahead leaves this body
+            rdPtr = ringLds + (size_t)rd * 1024 + laneOff;
+            rd_advance(RA);
+        }
+        ab[f % RA] = *(const frag*)(rdPtr + (f % RA) * 1024);
+        return a;
+    };
+    // acc[mt] += W(tile mt) * b.  Fragment order inside a GEMM: groups of G tiles, k-fragment-major
+    // inside a group, so that the MFMAs accumulating into one tile are G instructions apart.
     auto gemm_s = [&](auto mtTag, auto kfTag, auto bodyTag, auto bodypTag, int pos0, floatx4* acc, const frag* bfr) {
         constexpr int MT = decltype(mtTag)::value, KF = decltype(kfTag)::value;
-        constexpr int BODY = decltype(bodyTag)::value, BODYP = decltype(bodypTag)::value;
-        // fragment order inside a GEMM: groups of G tiles, k-fragment-major inside a group, so that
-        // the MFMAs accumulating into one tile are G instructions apart (no dependent-MFMA stall)
         constexpr int G = MT >= 4 ? 4 : MT;
 #pragma unroll
-        for (int mg = 0; mg < MT / G; mg++) {
+        for (int mg = 0; mg < MT / G; mg++)
 #pragma unroll
-            for (int kf = 0; kf < KF; kf++) {
+            for (int kf = 0; kf < KF; kf++)
 #pragma unroll
                 for (int mi = 0; mi < G; mi++) {
-                    const int mt = mg * G + mi;
-                    const int f = pos0 + (mg * KF + kf) * G + mi;
-                    if (f % CH == 0) {                                         // consumption enters a new chunk
-                        if (!firstChunk) asm volatile("s_barrier" ::: "memory");
-                        firstChunk = false;
-                    }
-                    const frag a = ab[f % RA];
-                    if (f % RA == 0) {
-                        // the next RA read-ahead fragments are contiguous in the ring (everything is
-                        // kept a multiple of RA): one address per group, immediates inside it
-                        if (f + RA == BODY) rd_advance(BODYP - BODY);          // read-ahead leaves this body
-                        rdPtr = ringLds + (size_t)rd * 1024 + laneOff;
-                        rd_advance(RA);
-                    }
-                    ab[f % RA] = *(const frag*)(rdPtr + (f % RA) * 1024);
-                    acc[mt] = mma(a, bfr[kf], acc[mt]);
+                    const frag a = next_frag(bodyTag, bodypTag, pos0 + (mg * KF + kf) * G + mi);
+                    acc[mg * G + mi] = mma(a, bfr[kf], acc[mg * G + mi]);
                 }
-            }
-        }
     };
     using IC_FL = std::integral_constant<int, C::FL>;
     using IC_FLP = std::integral_constant<int, C::FLP>;
@@ -287,15 +291,22 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
 
         // ---- embedding (nv_wavenet_reference.cpp:42-56) ---------------------------------------
         floatx4 x[RT];
+        {
+            quad qp[RT], qc[RT];     // all gathers in flight before any of the math
 #pragma unroll
-        for (int tt = 0; tt < RT; tt++) {
-            floatx4 ev = quad_to_f32(*(const quad*)(embPrev + (size_t)yPrev * R + tt * 16 + g * 4)) +
-                         quad_to_f32(*(const quad*)(embCur + (size_t)yCur * R + tt * 16 + g * 4));
-            if (p.tanhEmbed) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) ev[r] = tanh_t<F16>(ev[r]);
+            for (int tt = 0; tt < RT; tt++) {
+                qp[tt] = *(const quad*)(embPrev + (size_t)yPrev * R + tt * 16 + g * 4);
+                qc[tt] = *(const quad*)(embCur + (size_t)yCur * R + tt * 16 + g * 4);
             }
-            x[tt] = ev;
+#pragma unroll
+            for (int tt = 0; tt < RT; tt++) {
+                floatx4 ev = quad_to_f32(qp[tt]) + quad_to_f32(qc[tt]);
+                if (p.tanhEmbed) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) ev[r] = tanh_t<F16>(ev[r]);
+                }
+                x[tt] = ev;
+            }
         }
 
         floatx4 skip[ST];
@@ -304,6 +315,11 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
         WN_SMARK(0)
 
         // ---- L dilated layers (nv_wavenet_reference.cpp:58-92) -------------------------------
+        frag hb[KF_R];          // h of the previous layer as B fragments (zero before layer 0)
+#pragma unroll
+        for (int k = 0; k < KF_R; k++)
+#pragma unroll
+            for (int e = 0; e < P::EPL; e++) hb[k][e] = (elem)0.f;
         Dil dl = dil_first();
         for (int l = 0; l < L; l++) {
             const float* bl = biasLds + l * C::BIAS_L;
@@ -339,16 +355,39 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
             gemm_s(IC_R2T{}, IC_KFR{}, IC_FL{}, IC_FLP{}, C::O_PREV, acc, xp);
             gemm_s(IC_R2T{}, IC_KFR{}, IC_FL{}, IC_FLP{}, C::O_CUR, acc, xb);
             WN_SMARK(2)
-#pragma unroll
-            for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                for (int e = 0; e < P::EPL; e++) acc[k * P::TPF + (e >> 2)][e & 3] += (float)cd[k][e];
 
-            // gate
+            // gate(l)  h = tanh(z_lo + Lh) * sigmoid(z_hi + Lh)  interleaved, value by value, with the
+            // skip GEMM of layer l-1 (skip <- Wskip h_{l-1} + skip): the MFMAs run under the VALU work
             floatx4 h[RT];
+            {
+                constexpr int NSK = C::F_SKIP, NV = RT * 4, GS = ST >= 4 ? 4 : ST;
+                int vdone = 0;
 #pragma unroll
-            for (int tt = 0; tt < RT; tt++) h[tt] = gate4<F16>(acc[tt], acc[tt + RT]);
-            frag hb[KF_R];
+                for (int sidx = 0; sidx < NSK; sidx++) {
+                    const int mg = sidx / (KF_R * GS), kf = (sidx / GS) % KF_R, mi = sidx % GS;
+                    const frag a = next_frag(IC_FL{}, IC_FLP{}, C::O_SKIP + sidx);
+                    skip[mg * GS + mi] = mma(a, hb[kf], skip[mg * GS + mi]);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        if (v == vdone && (v + 1) * NSK <= (sidx + 1) * NV) {
+                            const int tt = v >> 2, r = v & 3;
+                            const float zl = acc[tt][r] + (float)cd[tt / P::TPF][(tt % P::TPF) * 4 + r];
+                            const float zh = acc[tt + RT][r] + (float)cd[(tt + RT) / P::TPF][((tt + RT) % P::TPF) * 4 + r];
+                            h[tt][r] = tanh_t<F16>(zl) * sigmoid_f(zh);
+                            vdone = v + 1;
+                        }
+                    }
+                    // pin the interleaving: without this the scheduler clusters all MFMAs first
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (dumpNow && valid && l > 0) {
+                const float* bp = biasLds + (l - 1) * C::BIAS_L + 3 * R;           // running bias sum
+#pragma unroll
+                for (int i = 0; i < ST; i++)
+                    *(floatx4*)(p.skipOut + ((size_t)(l - 1) * p.maxBatch + b) * S + i * 16 + g * 4) =
+                        skip[i] + *(const floatx4*)(bp + i * 16 + g * 4);
+            }
             to_bfrags<RT>(h, hb);
 
             // residual: x <- Wres h + Bres + x
@@ -359,32 +398,20 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
             gemm_s(IC_RT{}, IC_KFR{}, IC_FL{}, IC_FLP{}, C::O_RES, xa, hb);
 #pragma unroll
             for (int tt = 0; tt < RT; tt++) x[tt] = xa[tt];
-
-            // skip: skip <- Wskip h + skip   (biases: running sums, added at the head / in dumps)
             WN_SMARK(4)
-            gemm_s(IC_ST{}, IC_KFR{}, IC_FL{}, IC_FLP{}, C::O_SKIP, skip, hb);
-            WN_SMARK(5)
-
             if (dumpNow && valid) {
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++)
                     *(floatx4*)(p.xtOut + ((size_t)l * p.maxBatch + b) * R + tt * 16 + g * 4) = x[tt];
-#pragma unroll
-                for (int i = 0; i < ST; i++) {
-                    floatx4 v = skip[i] + *(const floatx4*)(bl + 3 * R + i * 16 + g * 4);
-                    if (l == L - 1) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
-                    }
-                    *(floatx4*)(p.skipOut + ((size_t)l * p.maxBatch + b) * S + i * 16 + g * 4) = v;
-                }
             }
+            WN_SMARK(5)
             dl = dl1;
         }
 
         WN_SMARK(6)
         // ---- output head (nv_wavenet_reference.cpp:94-104) -----------------------------------
         frag zb[KF_A];
+        gemm_s(IC_ST{}, IC_KFR{}, IC_FH{}, IC_FHP{}, C::H_SKIP, skip, hb);   // skip GEMM of the last layer
         {
             frag sb[KF_S];
             {
@@ -394,13 +421,15 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
                     skip[i] += *(const floatx4*)(bs + i * 16 + g * 4);
 #pragma unroll
                     for (int r = 0; r < 4; r++) skip[i][r] = __builtin_fmaxf(skip[i][r], 0.f);
+                    if (dumpNow && valid)   // the oracle applies the ReLU to the last layer's skipOut in place
+                        *(floatx4*)(p.skipOut + ((size_t)(L - 1) * p.maxBatch + b) * S + i * 16 + g * 4) = skip[i];
                 }
                 to_bfrags<ST>(skip, sb);
             }
             floatx4 zs[AT];
 #pragma unroll
             for (int i = 0; i < AT; i++) zs[i] = *(const floatx4*)(headBias + i * 16 + g * 4);
-            gemm_s(IC_AT{}, IC_KFS{}, IC_FH{}, IC_FHP{}, 0, zs, sb);
+            gemm_s(IC_AT{}, IC_KFS{}, IC_FH{}, IC_FHP{}, C::H_ZS, zs, sb);
 #pragma unroll
             for (int i = 0; i < AT; i++)
 #pragma unroll
@@ -415,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
         floatx4 za[AT];
 #pragma unroll
         for (int i = 0; i < AT; i++) za[i] = *(const floatx4*)(headBias + A + g * (A / 4) + i * 4);
-        gemm_s(IC_AT{}, IC_KFA{}, IC_FH{}, IC_FHP{}, C::F_ZS, za, zb);
+        gemm_s(IC_AT{}, IC_KFA{}, IC_FH{}, IC_FHP{}, C::H_ZA, za, zb);
         if (dumpNow && valid) {
 #pragma unroll
             for (int i = 0; i < AT; i++) *(floatx4*)(p.za + (size_t)b * A + g * (A / 4) + i * 4) = za[i];
