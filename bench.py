@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (0 = find the max real-time batch)")
     ap.add_argument("--samples", type=int, default=0, help="samples per step (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
     args = ap.parse_args()
 
     import torch
@@ -161,10 +162,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from nv_wavenet_amd.sharding import gather_samples
     w = make_weights()
@@ -191,6 +196,8 @@ def main():
                     break
             choice[0] = best
         if world > 1:
+            if args.backend != "nccl":
+                choice = choice.cpu()
             dist.broadcast(choice, 0)
         B = int(choice.item())
     N = args.samples or samples_per_step_for(B)
@@ -247,7 +254,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps

@@ -44,14 +44,16 @@ def gather_samples(y_local, total_batch, group=None, async_op=False):
     if y_local.shape[0] != mx:
         pad = torch.zeros(mx - y_local.shape[0], N, dtype=y_local.dtype, device=y_local.device)
         y_local = torch.cat([y_local, pad], 0)
+    dev = y_local.device
+    if dist.get_backend(group) == "gloo" and dev.type != "cpu":
+        y_local = y_local.cpu()            # gloo (CPU tests / smoke runs): stage through host memory
     out = torch.empty(world * mx, N, dtype=y_local.dtype, device=y_local.device)
     work = dist.all_gather_into_tensor(out, y_local.contiguous(), group=group, async_op=async_op)
 
     def finish():
         if work is not None:
             work.wait()
-        if all(s == mx for s in sizes):
-            return out
-        return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], 0)
+        res = out if all(s == mx for s in sizes) else torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], 0)
+        return res.to(dev) if res.device != dev else res
 
     return (None, finish) if async_op else (finish(), None)
