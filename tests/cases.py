@@ -41,6 +41,8 @@ EXTRA_CASES = [
     Case("C3_R64S256A256_L20_B21", 31, [], Shape(64, 256, 256, 20, 21, 40, 16), 3, 1, 16),
     # C4 shape: R=128, 30 layers
     Case("C4_R128S256A256_L30_B8", 50, [], Shape(128, 256, 256, 30, 8, 48, 16), 2, 1, 20),
+    # R=256: only the reference's perf harness instantiates it (nv_wavenet_perf.cu:156-166)
+    Case("R256S256A256_L6_B5", 90, [], Shape(256, 256, 256, 6, 5, 24, 8), 3, 1, 10),
 ]
 
 ALL_CASES = REF_CASES + EXTRA_CASES
