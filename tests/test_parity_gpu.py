@@ -100,7 +100,8 @@ def test_run_equals_run_chunks_and_partial_batch():
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", ["R64S256A256_impl3", "R64S128A256_impl1", "R32S128A256_impl1", "R128S256A256_impl3"])
+@pytest.mark.parametrize("name", ["R64S256A256_impl3", "R64S128A256_impl1", "R32S128A256_impl1", "R128S256A256_impl3",
+                                  "R64S128A512_impl3", "R128S256A1024_impl3", "R256S256A256_L6_B5"])
 def test_fp16_engine_against_fp32_oracle(name, mode):
     """fp16 parity is unpinned by the reference (no test runs half). Stated tolerance: with every
     weight / bias / embedding / conditioning value rounded to fp16 and fed to BOTH sides, the fp16
@@ -114,7 +115,7 @@ def test_fp16_engine_against_fp32_oracle(name, mode):
     e = util.make_engine(case, t, precision=16, mode=mode)
     y_ref = o.run(s.N)
     y = np.full((s.B, s.N), -1, dtype=np.int32)
-    assert e.run_chunks(7, None, s.N, s.B, y, 4)
+    assert e.run_chunks(7, None, s.N, s.B, y, _bspb(s.B))
     e.synchronize()
     ref, got = o.getters(), util.engine_getters(e, s.L)
     same = np.all(y == y_ref, axis=1)
