@@ -125,22 +125,27 @@ protected:
         gpuErrChk(hipGetLastError());
         gpuErrChk(hipStreamSynchronize(0));
     }
-    template <int BT> static size_t ldsNeed(int L, bool emb) { return wn::Cfg<F16, R, S, A, BT>::ldsBytes(L, emb); }
+    template <int BT> static size_t ldsNeed(int L, int embTables) { return wn::Cfg<F16, R, S, A, BT>::ldsBytes(L, embTables); }
     static constexpr size_t kLdsMax = 160 * 1024;
-    template <int BT> bool ldsFits() const { return ldsNeed<BT>(m_numLayers, false) <= kLdsMax; }
-    template <int BT> bool embFits() const { return ldsNeed<BT>(m_numLayers, true) <= kLdsMax; }
-    template <int BT, bool EMB> bool launchK(const wn::Params& p, int tiles, hipStream_t stream) {
+    template <int BT> bool ldsFits() const { return ldsNeed<BT>(m_numLayers, 0) <= kLdsMax; }
+    // how many embedding tables fit in LDS beside everything else: 2, 1 (current tap) or 0
+    template <int BT> int embTables() const {
+        return ldsNeed<BT>(m_numLayers, 2) <= kLdsMax ? 2 : ldsNeed<BT>(m_numLayers, 1) <= kLdsMax ? 1 : 0;
+    }
+    template <int BT, bool EMB> bool launchK(wn::Params& p, int tiles, int nEmb, hipStream_t stream) {
         using CB = wn::Cfg<F16, R, S, A, BT>;
         const int grid = (tiles + BT - 1) / BT;
+        p.embLds = nEmb;
         hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB>), dim3(grid), dim3(CB::THREADS),
-                           ldsNeed<BT>(m_numLayers, EMB), stream, p);
+                           ldsNeed<BT>(m_numLayers, nEmb), stream, p);
         return hipGetLastError() == hipSuccess;
     }
-    template <int BT> bool launch(const wn::Params& p, int tiles, hipStream_t stream) {
-        return embFits<BT>() ? launchK<BT, true>(p, tiles, stream) : launchK<BT, false>(p, tiles, stream);
+    template <int BT> bool launch(wn::Params& p, int tiles, hipStream_t stream) {
+        const int nEmb = embTables<BT>();
+        return nEmb ? launchK<BT, true>(p, tiles, nEmb, stream) : launchK<BT, false>(p, tiles, 0, stream);
     }
     template <int BT, bool EMB> void allowLdsK() {
-        const size_t need = ldsNeed<BT>(m_numLayers, EMB);
+        const size_t need = ldsNeed<BT>(m_numLayers, EMB ? embTables<BT>() : 0);
         if (need <= kLdsMax)
             gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
@@ -236,7 +241,7 @@ public:
 
         if (!ldsFits<1>()) {
             fprintf(stderr, "nvWavenetInfer: R=%d S=%d A=%d with %d layers needs %zu bytes of LDS (> 160 KiB)\n", R, S,
-                    A, numLayers, ldsNeed<1>(numLayers, false));
+                    A, numLayers, ldsNeed<1>(numLayers, 0));
             exit(1);
         }
         allowLds<1>();
@@ -453,6 +458,7 @@ public:
         p.tanhEmbed = m_tanhEmbed ? 1 : 0;
         p.dump = dumpActivations ? 1 : 0;
         // rings + conditioning of many tiles stream through HBM: keep them from evicting the weights
+        p.embLds = 0;
         p.ntStream = ((size_t)((batch_size + 15) / 16) * m_ringSlots * R * 16 * sizeof(elem) > ((size_t)16 << 20)) ? 1 : 0;
         if (p.count <= 0) return true;
 

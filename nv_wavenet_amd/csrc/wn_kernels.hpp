@@ -103,15 +103,21 @@ struct Cfg {
     // depth of the per-wave weight prefetch ring.  Deeper is NOT better: measured on MI355X, 18 in
     // flight per wave is 12% slower than 9 (the wave's VMEM queue fills and instruction issue stalls).
     static constexpr int PF = pick_pf(FLW, 12);
-    static_assert(FLW % PF == 0 && PF <= FHW, "prefetch ring must divide the layer stream");
+    static_assert(FLW % PF == 0 && PF <= FW_ZS, "prefetch ring must divide the layer stream");
     // The head's weights (FHW fragments per wave) stay RESIDENT in registers for the whole launch
     // when they fit the otherwise idle accumulator half of the register file (4 regs/fragment):
     // the head then needs no weight stream at all (it is purely stream-bound otherwise).
+    // HR = number of resident fragments (the tail of the head: all of it, or the A x A matrix only
+    // when registers are scarcer, e.g. two tiles per workgroup); HS = head fragments still streamed.
 #ifdef WN_ABL_NOHEADRES
-    static constexpr bool HEADRES = false;
+    static constexpr int HR = 0;
 #else
-    static constexpr bool HEADRES = F16 && (FHW * 4 <= 256) && (BT == 1 || FHW * 4 <= 192);
+    static constexpr int HR = !F16 ? 0
+                              : BT == 1 ? (FHW * 4 <= 256 ? FHW : (FW_ZA * 4 <= 256 ? FW_ZA : 0))
+                                        : (FW_ZA * 4 <= 128 ? FW_ZA : 0);
 #endif
+    static constexpr int HS = FHW - HR;
+    static constexpr bool HEADRES = HS == 0;              // the stream cycles over the layers only
     static constexpr int FRAG_ELEMS = 64 * EPL;
     static constexpr int BIAS_L = 3 * R + S;               // fp32 biases per layer: Bh | Bres | Bskip
     static constexpr int COND_FR = 2 * HTW / TPF;          // conditioning fragments per (sample,layer,tile,wave)
@@ -129,9 +135,9 @@ struct Cfg {
     static constexpr int OFF_X = 0, OFF_H = OFF_X + XBUF, OFF_SK = OFF_H + HBUF, OFF_ZS = OFF_SK + SKBUF;
     static constexpr int OFF_LG = OFF_ZS + ZSBUF, OFF_Y = OFF_LG + LGBUF, LDS_FIXED = OFF_Y + YBUF;
     // + optionally both embedding tables (T_data) behind the bias table
-    static size_t ldsBytes(int L, bool embLds) {
+    static size_t ldsBytes(int L, int embTables) {      // embTables: 0, 1 (current tap only) or 2
         return (size_t)LDS_FIXED + ((size_t)L * BIAS_L + 2 * A) * sizeof(float) +
-               (embLds ? (size_t)2 * A * R * sizeof(typename P::elem) : 0);
+               (size_t)embTables * A * R * sizeof(typename P::elem);
     }
     // per-wave stream in memory: [L][FLW] layers | [FHW] head
     __host__ __device__ static size_t headOffsetFrags(int L) { return (size_t)L * FLW; }
@@ -185,6 +191,7 @@ struct Params {
     int tanhEmbed;
     int dump;
     int ntStream;            // non-temporal ring / conditioning traffic (large batches)
+    int embLds;              // embedding tables held in LDS: 0 none, 1 current tap, 2 both
 };
 
 // ------------------------------------------------------------------------------------------
@@ -461,16 +468,18 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     const elem* embPrev = (const elem*)p.embPrev;
     const elem* embCur = (const elem*)p.embCur;
     if constexpr (EMBLDS) {
+        // p.embLds tables fit in LDS: the current tap's (its gather follows every pick, on the
+        // critical path) and, if there is room, the older tap's (gathered one sample early)
         elem* const embLds = (elem*)(biasLds + L * C::BIAS_L + 2 * A);
-        const floatx4* s0 = (const floatx4*)p.embPrev;
-        const floatx4* s1 = (const floatx4*)p.embCur;
+        const floatx4* s0 = (const floatx4*)p.embCur;
+        const floatx4* s1 = (const floatx4*)p.embPrev;
         constexpr int CH = (int)(A * R * sizeof(elem) / 16);
         for (int i = tid; i < CH; i += C::THREADS) {
             ((floatx4*)embLds)[i] = s0[i];
-            ((floatx4*)embLds)[CH + i] = s1[i];
+            if (p.embLds > 1) ((floatx4*)embLds)[CH + i] = s1[i];
         }
-        embPrev = embLds;
-        embCur = embLds + A * R;
+        embCur = embLds;
+        if (p.embLds > 1) embPrev = embLds + A * R;
         __syncthreads();   // the tables are complete before the first gather below
     }
 
@@ -492,10 +501,11 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 
     // ---- prefetch of the dilated input + conditioning of (sample tn, layer ln) ----------------
     // ---- resident head weights ------------------------------------------------------------------
-    frag hw[C::HEADRES ? FHW : 1];
-    if constexpr (C::HEADRES) {
+    constexpr int HR = C::HR, HS = C::HS;
+    frag hw[HR ? HR : 1];
+    if constexpr (HR > 0) {
 #pragma unroll
-        for (int i = 0; i < FHW; i++) hw[i] = *(const frag*)(whead + (size_t)i * 1024 + laneOff);
+        for (int i = 0; i < HR; i++) hw[i] = *(const frag*)(whead + (size_t)(HS + i) * 1024 + laneOff);
     }
 
     // ---- prefetch of the dilated input + conditioning, TWO layers ahead (HBM latency of the
@@ -761,8 +771,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int i = 0; i < ATW; i++) zs[bt][i] = *(const floatx4*)(headBias + (w + NW * i) * 16 + g * 4);
             }
-            if constexpr (C::HEADRES) gemm_res<F16, BT, ATW, KF_S>(hw, 0, zs, sb);
-            else gemm<F16, PF, FHW, BT, ATW, KF_S>(ws, 0, whead, wbase, laneOff, zs, sb);
+            if constexpr (HS == 0) gemm_res<F16, BT, ATW, KF_S>(hw, 0, zs, sb);
+            else gemm<F16, PF, HS, BT, ATW, KF_S>(ws, 0, whead, wbase, laneOff, zs, sb);
         }
 #pragma unroll
         for (int bt = 0; bt < BT; bt++)
@@ -785,8 +795,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 for (int i = 0; i < ATW; i++)
                     za[bt][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
             }
-            if constexpr (C::HEADRES) gemm_res<F16, BT, ATW, KF_A>(hw, C::FW_ZS, za, zb);
-            else gemm<F16, PF, FHW, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zb);
+            if constexpr (HR >= C::FW_ZA) gemm_res<F16, BT, ATW, KF_A>(hw, C::FW_ZS - HS, za, zb);
+            else gemm<F16, PF, HS, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zb);
             // logits -> LDS [utt][row] (row stride padded by 4 floats: conflict-free b128 writes)
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
@@ -799,10 +809,10 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         }
         WN_TMARK(8)
         // the head is not a multiple of the ring: rotate the ring back into phase
-        if constexpr (!C::HEADRES && FHW % PF != 0) {
+        if constexpr (HS > 0 && HS % PF != 0) {
             frag tmp[PF];
 #pragma unroll
-            for (int i = 0; i < PF; i++) tmp[i] = ws.buf[(i + FHW) % PF];
+            for (int i = 0; i < PF; i++) tmp[i] = ws.buf[(i + HS) % PF];
 #pragma unroll
             for (int i = 0; i < PF; i++) ws.buf[i] = tmp[i];
         }
