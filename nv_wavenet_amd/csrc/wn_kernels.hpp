@@ -132,8 +132,11 @@ struct Cfg {
     static constexpr int LROW = A + 4;                     // padded logits row (floats)
     static constexpr int LGBUF = BT * 16 * LROW * 4;
     static constexpr int YBUF = align16(BT * 16 * 4);
+    static constexpr int XPBUF = XBUF;                     // dilated tap x[t-d] as B fragments (shared by the waves)
+    static constexpr int XPW = (KF_R + NW - 1) / NW;       // ring fragments owned (stored AND re-loaded) by one wave
     static constexpr int OFF_X = 0, OFF_H = OFF_X + XBUF, OFF_SK = OFF_H + HBUF, OFF_ZS = OFF_SK + SKBUF;
-    static constexpr int OFF_LG = OFF_ZS + ZSBUF, OFF_Y = OFF_LG + LGBUF, LDS_FIXED = OFF_Y + YBUF;
+    static constexpr int OFF_LG = OFF_ZS + ZSBUF, OFF_Y = OFF_LG + LGBUF, OFF_XP = OFF_Y + YBUF;
+    static constexpr int LDS_FIXED = OFF_XP + XPBUF;
     // + optionally both embedding tables (T_data) behind the bias table
     static size_t ldsBytes(int L, int embTables) {      // embTables: 0, 1 (current tap only) or 2
         return (size_t)LDS_FIXED + ((size_t)L * BIAS_L + 2 * A) * sizeof(float) +
@@ -421,6 +424,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     char* const zsbuf = lds + C::OFF_ZS;
     float* const lgbuf = (float*)(lds + C::OFF_LG);
     int* const ybuf = (int*)(lds + C::OFF_Y);
+    char* const xpbuf = lds + C::OFF_XP;
     float* const biasLds = (float*)(lds + C::LDS_FIXED);
 
     const int tid = threadIdx.x;
@@ -510,7 +514,10 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 
     // ---- prefetch of the dilated input + conditioning, TWO layers ahead (HBM latency of the
     //      conditioning stream exceeds half a layer) ---------------------------------------------
-    frag xpA[BT][KF_R], xpB[BT][KF_R];          // next layer / the one after
+    // Each wave re-loads only the ring fragments it stored itself (k % NW == w) and the waves share
+    // them through LDS: 1/NW of the ring loads per wave instead of all of them.
+    constexpr int XPW = C::XPW;
+    frag xpA[BT][XPW], xpB[BT][XPW];            // next layer / the one after
     frag cdA[BT][C::COND_FR], cdB[BT][C::COND_FR];
     // per-(sample,layer) strides in bytes; everything here is wave-uniform (SALU)
     const size_t condStride = (size_t)p.tiles * NW * C::COND_FR * 1024;            // one (sample,layer) row
@@ -519,25 +526,51 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     char* const ringMine = (char*)p.ring + (size_t)tile0 * ringTile;
     // loads (sample tn, layer ln) into (xd, cdd); ln may run past L-1 into the next sample.
     // The conditioning buffer carries one padding sample, so (tEnd, 0..1) stays in bounds.
-    auto prefetch = [&](int tn, int ln, Dil dl, frag (&xd)[BT][KF_R], frag (&cdd)[BT][C::COND_FR]) {
-#ifdef WN_ABL_NOPREFETCH
-        if (tn != p.initSample || ln > 1) return;
-#endif
+    auto prefetch = [&](int tn, int ln, Dil dl, frag (&xd)[BT][XPW], frag (&cdd)[BT][C::COND_FR]) {
         if (ln >= L) { ln -= L; tn += 1; }
         const unsigned slot = (unsigned)(dl.off + (tn & (dl.d - 1)));
         const char* rp0 = ringMine + (size_t)slot * (KF_R * 1024);
         const char* cp0 = condMine + ((size_t)tn * L + ln) * condStride;
 #pragma unroll
         for (int bt = 0; bt < BT; bt++) {
+#ifndef WN_ABL_NOXP
 #pragma unroll
-            for (int k = 0; k < KF_R; k++) xd[bt][k] = ld_stream((const frag*)(rp0 + bt * ringTile + k * 1024 + laneOff), nt);
+            for (int i = 0; i < XPW; i++) {
+                const int k = w + NW * i;
+                if (k < KF_R) xd[bt][i] = ld_stream((const frag*)(rp0 + bt * ringTile + (size_t)k * 1024 + laneOff), nt);
+            }
+#else
+            // timing experiment: a value the compiler cannot fold (keeps all downstream work alive)
+#pragma unroll
+            for (int i = 0; i < XPW; i++)
+#pragma unroll
+                for (int e = 0; e < P::EPL; e++) xd[bt][i][e] = (elem)(float)(tn + i);
+#endif
+#ifndef WN_ABL_NOCOND
 #pragma unroll
             for (int k = 0; k < C::COND_FR; k++)
                 cdd[bt][k] = ld_stream((const frag*)(cp0 + (size_t)bt * NW * C::COND_FR * 1024 + k * 1024 + laneOff), nt);
+#else
+#pragma unroll
+            for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                for (int e = 0; e < P::EPL; e++) cdd[bt][k][e] = (elem)(float)(ln + k) * (elem)0.001f;
+#endif
         }
     };
     prefetch(p.initSample, 0, dil_first(), xpA, cdA);
     prefetch(p.initSample, 1, dil_next(dil_first(), p.maxDilation, false), xpB, cdB);
+    // publish this wave's fragments of the NEXT layer's dilated tap (held in xpA) to LDS
+    auto publish_xp = [&]() {
+#pragma unroll
+        for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+            for (int i = 0; i < XPW; i++) {
+                const int k = w + NW * i;
+                if (k < KF_R) *(frag*)(xpbuf + ((bt * KF_R + k) * 64 + lane) * 16) = xpA[bt][i];
+            }
+    };
+    publish_xp();   // layer 0 of the first sample (ordered by the embedding barrier)
 
     __syncthreads();   // bias table visible
 
@@ -645,20 +678,22 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     }
                 }
             }
-            // dilated tap: x_l[t-d] was prefetched; zero before the start (reference :287)
+            // dilated tap: x_l[t-d] was prefetched and published to LDS by its owners during the
+            // previous layer; zero before the start (reference :287)
             frag xp[BT][KF_R];
             frag cd[BT][C::COND_FR];
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) {
+                lds_get_frags<F16, KF_R>(xpbuf + bt * KF_R * 1024, lane, xp[bt]);
 #pragma unroll
                 for (int k = 0; k < KF_R; k++) {
-                    xp[bt][k] = xpA[bt][k];
                     if (!havePrev) {
 #pragma unroll
                         for (int e = 0; e < P::EPL; e++) xp[bt][k][e] = (elem)0.f;
                     }
-                    xpA[bt][k] = xpB[bt][k];
                 }
+#pragma unroll
+                for (int i = 0; i < XPW; i++) xpA[bt][i] = xpB[bt][i];
 #pragma unroll
                 for (int k = 0; k < C::COND_FR; k++) {
                     cd[bt][k] = cdA[bt][k];
@@ -728,6 +763,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 }
             }
             WN_TMARK(6)
+            publish_xp();   // dilated tap of layer l+1 (layer 0 of the next sample after the last layer)
             wg_barrier();   // x complete
             WN_TMARK(7)
         };
