@@ -35,12 +35,28 @@ REALTIME_KHZ = 24.0
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0                 # dense fp16/bf16 MFMA peak
 L2_PEAK_GBS = 34500.0                         # aggregate L2 bandwidth (guide, measured)
+LDS_PEAK_GBS = 256 * 256 * 2.4                # 256 B/clk/CU x 256 CUs x 2.4 GHz (guide, LDS section)
 
 # algorithmic work per sample per utterance (SURVEY.md 8d / BASELINE.md)
 MACS = L * (5 * R * R + S * R) + A * S + A * A
 FLOPS = 2 * MACS
 WEIGHT_BYTES = 2 * (L * (5 * R * R + S * R) + A * S + A * A)     # fp16 weights streamed per tile pass
 HBM_BYTES = 2 * 2 * R * L + 4 + 4                                # cond (fp16) + selector + yOut
+
+
+def lds_bytes_per_sample(stream_mode, bt=1):
+    """Algorithmic LDS bytes moved per generated sample per WORKGROUP (fp16).
+    wg kernel (4 waves on bt tiles): per layer every wave reads the x, x[t-d] and h fragment images
+    (R/32 KiB each) and its bias quads, and writes its quarter of h, x and the dilated tap; the head
+    moves skip / zs images (S/32, A/32 KiB, read by all 4 waves) and the fp32 logits once each way.
+    stream kernel (4 consumer waves, one tile each): the whole weight stream is written to LDS once
+    by LDS-DMA and read once by every consumer; activations never leave registers."""
+    kf = lambda n: n // 32 * 1024
+    if stream_mode:
+        return 5 * WEIGHT_BYTES + 4 * (16 * A * 4 * 2)
+    per_layer = bt * (4 * 3 * kf(R) + 3 * kf(R)) + 4 * 64 * 16 * 3        # exchanges + bias quads
+    head = bt * (5 * kf(S) + 5 * kf(A) + 2 * 16 * A * 4 + 2 * kf(R)) + 4 * 64 * 16 * (S // 64 + 2 * A // 64)
+    return L * per_layer + head
 
 
 def make_weights(seed=3):
@@ -110,37 +126,62 @@ def measure_khz(w, B, N, seed=11, mode=None):
     return N / ms
 
 
-def cpu_baseline(w, budget_s=20.0):
-    """The reference's CPU implementation on one host core, C3 shape, batch 16, bounded sample."""
+def cpu_run_once(w, n, B=16, seed=5):
+    """n samples of the C3 shape at batch B on the calling core: (seconds, kind)."""
     from oracle import oracle as O
-    B = 16
     kind = "reference" if O.have_ref() else "port"
     cls = O.RefOracle if kind == "reference" else O.Oracle
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(seed)
 
     class T:
         pass
     t = T()
     for k, v in w.items():
         setattr(t, k, v)
-    n_probe = 4
-    out = None
-    for n in (n_probe, None):
-        if n is None:
-            n = int(max(8, min(512, budget_s / per_sample)))
-        Lh = ((rng.random((n, L, B, 2 * R), dtype=np.float32) - 0.5) * (0.5 / R)).astype(np.float32)
-        sel = rng.random((n, B), dtype=np.float32) * 0.999
-        o = cls(L, B, n, R, S, A, MAXD)
-        o.set_model(t)
-        o.set_inputs(Lh, sel)
+    Lh = ((rng.random((n, L, B, 2 * R), dtype=np.float32) - 0.5) * (0.5 / R)).astype(np.float32)
+    sel = rng.random((n, B), dtype=np.float32) * 0.999
+    o = cls(L, B, n, R, S, A, MAXD)
+    o.set_model(t)
+    o.set_inputs(Lh, sel)
+    t0 = time.perf_counter()
+    o.run(n)
+    dt = time.perf_counter() - t0
+    o.close()
+    return dt, kind
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """The reference's CPU implementation (nv_wavenet_reference.cpp built into oracle/_ref), C3 shape,
+    batch 16, bounded sample: on ONE host core (the reference's own single-threaded path = the reported
+    value), then one instance per host core on independent batch slices, as
+    sub-object all_cores."""
+    import subprocess
+    B = 16
+    dt, kind = cpu_run_once(w, 4)
+    n = int(max(8, min(512, budget_s / (dt / 4))))
+    dt, kind = cpu_run_once(w, n)
+    out = dict(value=B * n / dt, unit="samples/s", cores=1, kind=kind,
+               sample="R%d/S%d/A%d L%d maxD%d fp32, batch %d x %d samples (%.1f s)" % (R, S, A, L, MAXD, B, n, dt),
+               khz_per_utterance=n / dt / 1e3)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, 64)
+    if cores > 1:
+        # separate interpreters (no torch, no HIP): a fork of this process would carry the GPU runtime
+        n2 = max(8, n // 2)
         t0 = time.perf_counter()
-        o.run(n)
-        dt = time.perf_counter() - t0
-        o.close()
-        per_sample = dt / n
-        out = dict(value=B * n / dt, unit="samples/s", cores=1, kind=kind,
-                   sample="R%d/S%d/A%d L%d maxD%d fp32, batch %d x %d samples (%.1f s)" % (R, S, A, L, MAXD, B, n, dt),
-                   khz_per_utterance=n / dt / 1e3)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n2), "--cpu-seed", str(i)],
+                                  stdout=subprocess.PIPE, cwd=ROOT) for i in range(cores)]
+        ok = 0
+        for pr in procs:
+            so, _ = pr.communicate()
+            ok += pr.returncode == 0 and b"cpu_worker_seconds" in so
+        wall = time.perf_counter() - t0
+        if ok == cores:
+            out["all_cores"] = dict(value=cores * B * n2 / wall, unit="samples/s", cores=cores,
+                                    sample="%d processes x batch %d x %d samples, wall %.1f s incl. start-up" % (cores, B, n2, wall))
     return out
 
 
@@ -153,7 +194,13 @@ def main():
     ap.add_argument("--samples", type=int, default=0, help="samples per step (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
+    ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seed", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        dt, _ = cpu_run_once(make_weights(), args.cpu_worker, seed=5 + args.cpu_seed)
+        print(json.dumps({"cpu_worker_seconds": dt}))
+        return
 
     import torch
     import torch.distributed as dist
@@ -286,10 +333,13 @@ def main():
                         kernel_ms=kern_ms,
                         hbm=dict(achieved=units * HBM_BYTES / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"),
                         l2_weight_stream=dict(achieved=passes * N * WEIGHT_BYTES / (kern_ms * 1e-3) / 1e9,
-                                              peak=L2_PEAK_GBS, unit="GB/s"))
+                                              peak=L2_PEAK_GBS, unit="GB/s"),
+                        lds=dict(achieved=passes * N * lds_bytes_per_sample(stream_mode) / (kern_ms * 1e-3) / 1e9,
+                                 peak=LDS_PEAK_GBS, unit="GB/s"))
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         roofline["hbm"]["frac"] = roofline["hbm"]["achieved"] / HBM_PEAK_GBS
         roofline["l2_weight_stream"]["frac"] = roofline["l2_weight_stream"]["achieved"] / L2_PEAK_GBS
+        roofline["lds"]["frac"] = roofline["lds"]["achieved"] / LDS_PEAK_GBS
         out = {
             "metric": "samples/sec (all GPUs) at the max real-time batch @24kHz, R64/S256/A256 20L fp16",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -134,8 +134,15 @@ struct Cfg {
     static constexpr int YBUF = align16(BT * 16 * 4);
     static constexpr int XPBUF = XBUF;                     // dilated tap x[t-d] as B fragments (shared by the waves)
     static constexpr int XPW = (KF_R + NW - 1) / NW;       // ring fragments owned (stored AND re-loaded) by one wave
+    // Large heads (A = 1024 in fp32): the fp32 logits take the place of the zs fragment image (one
+    // extra barrier between the last zs read and the first logit write), and the A x A GEMM reads its
+    // B fragments from LDS as it goes instead of holding all KF_A of them in registers.
+    static constexpr bool ALIAS_LG = ZSBUF + LGBUF > 100 * 1024;
+    static constexpr bool ZA_B_FROM_LDS = KF_A * BT * 4 > 128;
     static constexpr int OFF_X = 0, OFF_H = OFF_X + XBUF, OFF_SK = OFF_H + HBUF, OFF_ZS = OFF_SK + SKBUF;
-    static constexpr int OFF_LG = OFF_ZS + ZSBUF, OFF_Y = OFF_LG + LGBUF, OFF_XP = OFF_Y + YBUF;
+    static constexpr int OFF_LG = ALIAS_LG ? OFF_ZS : OFF_ZS + ZSBUF;
+    static constexpr int OFF_Y = ALIAS_LG ? OFF_ZS + (ZSBUF > LGBUF ? ZSBUF : LGBUF) : OFF_LG + LGBUF;
+    static constexpr int OFF_XP = OFF_Y + YBUF;
     static constexpr int LDS_FIXED = OFF_XP + XPBUF;
     // + optionally both embedding tables (T_data) behind the bias table
     static size_t ldsBytes(int L, int embTables) {      // embTables: 0, 1 (current tap only) or 2
@@ -379,6 +386,30 @@ WN_DEV void gemm(WStream<F16, PF>& ws, int pos0, const char* cur, const char* ne
                 auto a = take<F16, PF, WRAP>(ws, pos0 + (mg * KF + kf) * G + mi, cur, next, laneOff, rtWrapAt, rtWrapDelta);
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++) acc[bt][mt] = mma(a, b[bt][kf], acc[bt][mt]);
+            }
+        }
+    }
+}
+
+// same, with the B fragments read from their LDS image as they are needed (KF too large for registers)
+template <bool F16, int PF, int WRAP, int BT, int MT, int KF>
+WN_DEV void gemm_ldsb(WStream<F16, PF>& ws, int pos0, const char* cur, const char* next, unsigned laneOff,
+                      floatx4 (&acc)[BT][MT], const char* bimg, int lane) {
+    using frag = typename Prec<F16>::frag;
+    constexpr int G = MT >= 4 ? 4 : MT;
+#pragma unroll
+    for (int mg = 0; mg < MT / G; mg++) {
+#pragma unroll
+        for (int kf = 0; kf < KF; kf++) {
+            frag b[BT];
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) b[bt] = *(const frag*)(bimg + (((bt * KF + kf) * 64 + lane) << 4));
+#pragma unroll
+            for (int mi = 0; mi < G; mi++) {
+                const int mt = mg * G + mi;
+                auto a = take<F16, PF, WRAP>(ws, pos0 + (mg * KF + kf) * G + mi, cur, next, laneOff);
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++) acc[bt][mt] = mma(a, b[bt], acc[bt][mt]);
             }
         }
     }
@@ -823,16 +854,22 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         wg_barrier();
         {
             floatx4 za[BT][ATW];
-            frag zb[BT][KF_A];
 #pragma unroll
-            for (int bt = 0; bt < BT; bt++) {
-                lds_get_frags<F16, KF_A>(zsbuf + bt * KF_A * 1024, lane, zb[bt]);
+            for (int bt = 0; bt < BT; bt++)
 #pragma unroll
                 for (int i = 0; i < ATW; i++)
                     za[bt][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
+            if constexpr (C::ZA_B_FROM_LDS) {
+                static_assert(HR == 0, "the LDS-streamed head is for the large, non-resident heads");
+                gemm_ldsb<F16, PF, HS, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zsbuf, lane);
+            } else {
+                frag zb[BT][KF_A];
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_A>(zsbuf + bt * KF_A * 1024, lane, zb[bt]);
+                if constexpr (HR >= C::FW_ZA) gemm_res<F16, BT, ATW, KF_A>(hw, C::FW_ZS - HS, za, zb);
+                else gemm<F16, PF, HS, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zb);
             }
-            if constexpr (HR >= C::FW_ZA) gemm_res<F16, BT, ATW, KF_A>(hw, C::FW_ZS - HS, za, zb);
-            else gemm<F16, PF, HS, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zb);
+            if constexpr (C::ALIAS_LG) wg_barrier();   // every wave is done with the zs image
             // logits -> LDS [utt][row] (row stride padded by 4 floats: conflict-free b128 writes)
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
