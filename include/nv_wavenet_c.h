@@ -50,6 +50,19 @@ void nvw_set_layer_weights(nvw_engine* e, int layer, float* Wprev, float* Wcur, 
 void nvw_set_out_weights(nvw_engine* e, float* Wzs, float* Bzs, float* Wza, float* Bza);
 void nvw_set_inputs(nvw_engine* e, float* Lh, float* output_selectors);
 
+/* Extensions beyond the reference class (its "next" list: selectors drawn on the device instead of
+ * the host rand() table of pytorch/wavenet_infer.cu:92-94; mu-law expansion of pytorch/utils.py:62-70
+ * + pytorch/inference.py:58-60 done on the device):
+ *   nvw_set_conditioning   the conditioning half of setInputs (Lh [N][L][B][2R]; history := 128)
+ *   nvw_set_selector_seed  selectors = Philox4x32-10(counter {sample, utterance, 0, 0}, key = seed),
+ *                          top 24 bits of word 0 / 2^24; stays in force until the next nvw_set_inputs
+ *   nvw_set_audio_out      pcm_out: caller-owned [batch][samples] int16 (host or device), filled by
+ *                          the run calls wherever yOut is: int16(32768 * mu_law_decode(y, A)); NULL
+ *                          switches it off */
+void nvw_set_conditioning(nvw_engine* e, float* Lh);
+void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed);
+void nvw_set_audio_out(nvw_engine* e, short* pcm_out);
+
 int nvw_run(nvw_engine* e, int num_samples, int batch_size, int* yOut, int batch_size_per_block,
             int dump_activations, void* stream);
 int nvw_run_partial(nvw_engine* e, int init_sample, int num_samples, int batch_size, int* yOut,

@@ -3,7 +3,8 @@
 The product is the HIP library ``libwavenet_infer.so`` (C ABI in ``include/``); this package is the
 Python host side mirroring the reference's ``pytorch/`` wrapper:
 
-    nv_wavenet_amd.nv_wavenet      NVWaveNet, Impl, column_major   (pytorch/nv_wavenet.py)
+    nv_wavenet_amd.nv_wavenet      NVWaveNet, Impl, column_major   (pytorch/nv_wavenet.py);
+                                   NVWaveNetEngine, get_cond_input (engine kept alive)
     nv_wavenet_amd.nv_wavenet_ext  infer, num_*_channels           (pytorch/wavenet_infer_wrapper.cpp)
     nv_wavenet_amd.engine          WavenetEngine: the nvWavenetInfer class surface over ctypes
 

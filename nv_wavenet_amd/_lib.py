@@ -31,6 +31,9 @@ SIGNATURES = {
     "nvw_set_layer_weights": (None, [C.c_void_p, C.c_int] + [_fp] * 7),
     "nvw_set_out_weights": (None, [C.c_void_p] + [_fp] * 4),
     "nvw_set_inputs": (None, [C.c_void_p, _fp, _fp]),
+    "nvw_set_conditioning": (None, [C.c_void_p, _fp]),
+    "nvw_set_selector_seed": (None, [C.c_void_p, C.c_ulonglong]),
+    "nvw_set_audio_out": (None, [C.c_void_p, C.c_void_p]),
     "nvw_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_void_p]),
     "nvw_run_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_void_p]),
     "nvw_run_chunks": (C.c_int, [C.c_void_p, C.c_int, CONSUME_FN, C.c_void_p, C.c_int, C.c_int, _fp, C.c_int,

@@ -11,6 +11,9 @@ struct nvw_engine {
     virtual void setLayerWeights(int, float*, float*, float*, float*, float*, float*, float*) = 0;
     virtual void setOutWeights(float*, float*, float*, float*) = 0;
     virtual void setInputs(float*, float*) = 0;
+    virtual void setConditioning(float*) = 0;
+    virtual void setSelectorSeed(unsigned long long) = 0;
+    virtual void setAudioOut(short*) = 0;
     virtual bool run(int, int, int*, int, bool, hipStream_t) = 0;
     virtual bool run_partial(int, int, int, int*, int, bool, hipStream_t) = 0;
     virtual bool run_chunks(int, nvw_consume_fn, void*, int, int, int*, int, bool, hipStream_t) = 0;
@@ -32,6 +35,9 @@ struct EngineImpl : nvw_engine {
     }
     void setOutWeights(float* a, float* b, float* c, float* d) override { eng.setOutWeights(a, b, c, d); }
     void setInputs(float* Lh, float* sel) override { eng.setInputs(Lh, sel); }
+    void setConditioning(float* Lh) override { eng.setConditioning(Lh); }
+    void setSelectorSeed(unsigned long long seed) override { eng.setSelectorSeed(seed); }
+    void setAudioOut(short* pcm) override { eng.setAudioOut(pcm); }
     bool run(int n, int b, int* y, int bspb, bool dump, hipStream_t s) override {
         return eng.run(n, b, y, bspb, dump, s);
     }

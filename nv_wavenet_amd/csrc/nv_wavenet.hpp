@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
 #include <type_traits>
 #include <vector>
 
@@ -76,6 +77,13 @@ protected:
 
     float* m_stage;     // device staging for fp32 uploads from host pointers
     size_t m_stageElems;
+
+    // extensions beyond the reference: in-kernel selectors, int16 PCM output
+    bool m_useRng;
+    unsigned long long m_rngSeed;
+    short* m_pcm;       // [maxBatch][maxSamples] int16, allocated on first setAudioOut
+    short* m_mulaw;     // [A] PCM value of every sample index
+    short* m_pcmUser;   // caller's buffer (host or device), filled wherever yOut is
 
     static bool isDevicePtr(const void* ptr) {
         hipPointerAttribute_t attr;
@@ -161,7 +169,8 @@ public:
                    bool tanhEmbed = true)
         : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
-          m_num_samples_per_chunk(0), m_stage(NULL), m_stageElems(0) {
+          m_num_samples_per_chunk(0), m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL),
+          m_mulaw(NULL), m_pcmUser(NULL) {
         assert(numLayers >= 2 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
         m_tiles = ((batchSize + 15) / 16 + MAXBT - 1) / MAXBT * MAXBT;   // whole workgroups of MAXBT tiles
         {
@@ -271,6 +280,8 @@ public:
         gpuErrChk(hipFree(m_Za));
         gpuErrChk(hipFree(m_p));
         if (m_stage) gpuErrChk(hipFree(m_stage));
+        if (m_pcm) gpuErrChk(hipFree(m_pcm));
+        if (m_mulaw) gpuErrChk(hipFree(m_mulaw));
     }
 
     // ---- model upload: fp32 in, host or device pointers, data is copied ---------------------
@@ -322,6 +333,16 @@ public:
     // Lh: [maxSamples][L][maxBatch][2R] conditioning, outputSelectors: [maxSamples][maxBatch]
     // uniform draws; resets the sample history to 128 (nv_wavenet.cuh:417-422).
     void setInputs(float* Lh, float* outputSelectors) {
+        setConditioning(Lh);
+        m_useRng = false;
+        gpuErrChk(hipMemcpy(m_outputSelectors, outputSelectors, (size_t)m_maxSamples * m_maxBatch * sizeof(float),
+                            hipMemcpyDefault));
+    }
+
+    // ---- extensions beyond the reference --------------------------------
+    // The conditioning half of setInputs (also resets the history to 128); pair it with
+    // setSelectorSeed() and no [N][B] selector matrix is ever built or uploaded.
+    void setConditioning(float* Lh) {
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
         const size_t rows = (size_t)m_maxSamples * m_numLayers;
@@ -343,8 +364,38 @@ public:
             gpuErrChk(hipGetLastError());
             gpuErrChk(hipStreamSynchronize(0));
         }
-        gpuErrChk(hipMemcpy(m_outputSelectors, outputSelectors, (size_t)m_maxSamples * m_maxBatch * sizeof(float),
-                            hipMemcpyDefault));
+    }
+    // Selectors are drawn inside the kernel: Philox4x32-10, counter {sample, utterance, 0, 0}, key =
+    // seed (replaces the rand() table of pytorch/wavenet_infer.cu:92-94).  A later setInputs()
+    // returns to the uploaded table.
+    void setSelectorSeed(unsigned long long seed) {
+        m_useRng = true;
+        m_rngSeed = seed;
+    }
+    // int16 PCM beside the indices: pcm[b][t] = int16(32768 * mu_law_decode(y[b][t], A))
+    // (pytorch/utils.py:62-70, inference.py:58-60).  pcmOut: caller-owned [maxBatch][maxSamples]
+    // int16, host or device; filled by run / run_partial / run_chunks wherever yOut is; NULL disables.
+    void setAudioOut(short* pcmOut) {
+        m_pcmUser = pcmOut;
+        if (pcmOut && !m_pcm) {
+            gpuErrChk(hipMalloc(&m_pcm, (size_t)m_maxSamples * m_maxBatch * sizeof(short)));
+            gpuErrChk(hipMemset(m_pcm, 0, (size_t)m_maxSamples * m_maxBatch * sizeof(short)));
+            std::vector<short> table(A);
+            const double mu = (double)A - 1.0;
+            for (int y = 0; y < A; y++) {
+                const double signal = 2.0 * ((double)y / mu) - 1.0;
+                const double magnitude = (1.0 / mu) * (std::pow(1.0 + mu, std::fabs(signal)) - 1.0);
+                const double v = 32768.0 * (signal > 0 ? magnitude : (signal < 0 ? -magnitude : 0.0));
+                table[y] = (short)(int)v;   // truncation; the top bin wraps to -32768 like numpy's cast
+            }
+            gpuErrChk(hipMalloc(&m_mulaw, A * sizeof(short)));
+            gpuErrChk(hipMemcpy(m_mulaw, table.data(), A * sizeof(short), hipMemcpyHostToDevice));
+        }
+    }
+    void getAudioOut(short* pcm, int offset, int size, hipStream_t stream = 0) {
+        gpuErrChk(hipMemcpy2DAsync(pcm + offset, m_maxSamples * sizeof(short), m_pcm + offset,
+                                   m_maxSamples * sizeof(short), size * sizeof(short), m_maxBatch, hipMemcpyDefault,
+                                   stream));
     }
 
     // ---- debug getters: last generated sample's activations, reference layouts --------------
@@ -398,6 +449,7 @@ public:
             gpuErrChk(hipEventRecord(event_compute[j], stream_compute));
             gpuErrChk(hipStreamWaitEvent(stream_copy, event_compute[j], 0));
             if (yOut != NULL) getYOut(yOut, initSample, n, stream_copy);
+            if (m_pcmUser != NULL) getAudioOut(m_pcmUser, initSample, n, stream_copy);
             gpuErrChk(hipEventRecord(event_copy[j], stream_copy));
         }
         for (int j = 0; j < num_chunks; j++) {
@@ -459,6 +511,9 @@ public:
         p.dump = dumpActivations ? 1 : 0;
         // rings + conditioning of many tiles stream through HBM: keep them from evicting the weights
         p.embLds = 0;
+        p.useRng = m_useRng ? 1 : 0;
+        p.rngKey0 = (unsigned)m_rngSeed;
+        p.rngKey1 = (unsigned)(m_rngSeed >> 32);
         p.ntStream = ((size_t)((batch_size + 15) / 16) * m_ringSlots * R * 16 * sizeof(elem) > ((size_t)16 << 20)) ? 1 : 0;
         if (p.count <= 0) return true;
 
@@ -474,9 +529,18 @@ public:
             result = hipGetLastError() == hipSuccess;
         } else if (two && ldsFits<2>()) result = launch<2>(p, tiles, stream);
         else result = launch<1>(p, tiles, stream);
+        if (m_pcmUser != NULL) {
+            // the indices of a finished sample are final: the expansion is a per-element map of yOut
+            hipLaunchKernelGGL(wn::mulaw_pcm_kernel, dim3(gridFor((size_t)batch_size * p.count)), dim3(256), 0, stream,
+                               m_yOut, m_pcm, m_mulaw, batch_size, num_samples, p.initSample, p.count);
+            result = result && hipGetLastError() == hipSuccess;
+        }
         if (yOut != NULL) {
             gpuErrChk(hipMemcpyAsync(yOut, m_yOut, (size_t)m_maxSamples * m_maxBatch * sizeof(int), hipMemcpyDefault,
                                      stream));
+            if (m_pcmUser != NULL)
+                gpuErrChk(hipMemcpyAsync(m_pcmUser, m_pcm, (size_t)m_maxSamples * m_maxBatch * sizeof(short),
+                                         hipMemcpyDefault, stream));
         }
         return result;
     }

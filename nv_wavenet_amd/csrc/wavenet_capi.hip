@@ -64,6 +64,9 @@ void nvw_set_out_weights(nvw_engine* e, float* Wzs, float* Bzs, float* Wza, floa
     e->setOutWeights(Wzs, Bzs, Wza, Bza);
 }
 void nvw_set_inputs(nvw_engine* e, float* Lh, float* sel) { e->setInputs(Lh, sel); }
+void nvw_set_conditioning(nvw_engine* e, float* Lh) { e->setConditioning(Lh); }
+void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed) { e->setSelectorSeed(seed); }
+void nvw_set_audio_out(nvw_engine* e, short* pcmOut) { e->setAudioOut(pcmOut); }
 
 int nvw_run(nvw_engine* e, int num_samples, int batch_size, int* yOut, int bspb, int dump, void* stream) {
     return e->run(num_samples, batch_size, yOut, bspb, dump != 0, (hipStream_t)stream) ? 1 : 0;

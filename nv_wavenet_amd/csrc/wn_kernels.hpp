@@ -202,6 +202,8 @@ struct Params {
     int dump;
     int ntStream;            // non-temporal ring / conditioning traffic (large batches)
     int embLds;              // embedding tables held in LDS: 0 none, 1 current tap, 2 both
+    int useRng;              // selectors drawn in-kernel (Philox4x32-10) instead of read from `sel`
+    unsigned rngKey0, rngKey1;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -210,6 +212,29 @@ struct Params {
 
 WN_DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 WN_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// In-kernel selector of (sample t, utterance b): Philox4x32-10 (Random123) with counter {t,b,0,0},
+// top 24 bits of word 0 scaled to [0,1).  Replaces the host rand() table of
+// pytorch/wavenet_infer.cu:92-94; oracle/wavenet_oracle.c:nvw_philox_selectors is
+// the CPU restatement the tests compare against.
+WN_DEV float philox_selector(unsigned k0, unsigned k1, unsigned t, unsigned b) {
+    unsigned c0 = t, c1 = b, c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        if (r) {
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = l1;
+        c2 = n2;
+        c3 = l0;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
 
 // sigmoid: relative error of a few ulp (no cancellation)
 #ifndef WN_ABL_NOACT
@@ -629,7 +654,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         for (int bt = 0; bt < BT; bt++) {
             int sb = (tile0 + bt) * 16 + su;
             sb = sb < p.batch ? sb : p.batch - 1;
-            selv[bt] = p.sel[(size_t)t * p.maxBatch + sb];
+            selv[bt] = p.useRng ? philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)sb)
+                                : p.sel[(size_t)t * p.maxBatch + sb];
         }
 
         // ---- embedding (nv_wavenet_reference.cpp:42-56): each wave makes its own x tiles ------
@@ -974,6 +1000,19 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 p.yInPrev[ub[bt]] = yPrev[bt];
                 p.yInCur[ub[bt]] = yCur[bt];
             }
+    }
+}
+
+// mu-law expansion of the generated indices to int16 PCM (pytorch/utils.py:62-70 +
+// inference.py:58-60), columns [first, first+count) of the [batch][numSamples] buffers.  The value
+// depends on the index alone: a table of A entries computed on the host in float64 like numpy.
+static __global__ void mulaw_pcm_kernel(const int* __restrict__ yOut, short* __restrict__ pcm,
+                                        const short* __restrict__ table, int batch, int numSamples, int first,
+                                        int count) {
+    const size_t n = (size_t)batch * count;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t at = (i / count) * numSamples + first + (i % count);
+        pcm[at] = table[yOut[at]];
     }
 }
 

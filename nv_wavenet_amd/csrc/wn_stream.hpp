@@ -286,7 +286,8 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
     const int tEnd = p.initSample + p.count;
     for (int t = p.initSample; t < tEnd; t++) {
         const bool dumpNow = p.dump && (t == tEnd - 1);
-        const float selv = p.sel[(size_t)t * p.maxBatch + bc];
+        const float selv = p.useRng ? philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)bc)
+                                    : p.sel[(size_t)t * p.maxBatch + bc];
         WN_SMARK(11)
 
         // ---- embedding (nv_wavenet_reference.cpp:42-56) ---------------------------------------

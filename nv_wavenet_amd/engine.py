@@ -86,6 +86,32 @@ class WavenetEngine:
         assert (sel.numel() if hasattr(sel, "numel") else sel.size) == self.maxSamples * self.maxBatch
         lib.nvw_set_inputs(self._h, addr(Lh), addr(sel))
 
+    # ---- beyond the reference class (include/nv_wavenet_c.h, "extensions") ---------------------
+    def setConditioning(self, Lh):
+        """The conditioning half of setInputs; pair with setSelectorSeed (no selector matrix)."""
+        Lh = _f32(Lh)
+        n = self.maxSamples * self.numLayers * self.maxBatch * 2 * self.R
+        assert (Lh.numel() if hasattr(Lh, "numel") else Lh.size) == n, "Lh has the wrong size"
+        lib.nvw_set_conditioning(self._h, addr(Lh))
+
+    def setSelectorSeed(self, seed):
+        """Selectors are drawn in-kernel (Philox4x32-10, counter {sample, utterance, 0, 0}, key=seed)."""
+        lib.nvw_set_selector_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+    def setAudioOut(self, pcmOut):
+        """pcmOut: int16 [maxBatch][maxSamples] (numpy or CUDA tensor) filled wherever yOut is with
+        int16(32768 * mu_law_decode(y, A)); None switches it off."""
+        if pcmOut is not None:
+            if hasattr(pcmOut, "data_ptr"):
+                import torch
+                assert pcmOut.dtype == torch.int16
+            else:
+                assert pcmOut.dtype == np.int16 and pcmOut.flags["C_CONTIGUOUS"]
+            n = pcmOut.numel() if hasattr(pcmOut, "numel") else pcmOut.size
+            assert n >= self.maxBatch * self.maxSamples
+        self._pcm_keep = pcmOut
+        lib.nvw_set_audio_out(self._h, addr(pcmOut) if pcmOut is not None else None)
+
     # ---- run --------------------------------------------------------------------------------
     def _yout(self, yOut):
         if yOut is None:

@@ -219,3 +219,28 @@ class RefOracle(_Base):
 
 def crc32(a, c=0):
     return _lib("oracle").nvw_crc32(a.ctypes.data, a.nbytes, c)
+
+
+def philox4x32_10(ctr, key):
+    """Random123 Philox4x32-10 of one (counter, key) pair: 4 uint32 words."""
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    _lib("oracle").nvw_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def philox_selectors(seed, N, B):
+    """The [N][B] selector matrix the engine draws in-kernel for `seed` (wavenet_oracle.c)."""
+    sel = np.zeros((N, B), dtype=np.float32)
+    lib = _lib("oracle")
+    lib.nvw_philox_selectors.argtypes = [C.c_uint64, C.c_int, C.c_int, _fp]
+    lib.nvw_philox_selectors(int(seed), N, B, _f(sel))
+    return sel
+
+
+def mulaw_pcm_table(A):
+    """int16 PCM value of every sample index (pytorch/utils.py:62-70 + inference.py:58-60)."""
+    t = np.zeros(A, dtype=np.int16)
+    _lib("oracle").nvw_mulaw_pcm_table(A, t.ctypes.data_as(C.c_void_p))
+    return t

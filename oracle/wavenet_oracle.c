@@ -411,3 +411,50 @@ uint32_t nvw_crc32(const void* data, size_t n, uint32_t crc) {
     }
     return ~crc;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * SURVEY.md 8f rank 2 extensions (not in the reference's C++ path): checker side.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+ * SC'11; Random123 philox.h).  Pinned by Random123's known-answer vectors in
+ * tests/test_oracle_cpu.py.  This is what replaces libc rand() of pytorch/wavenet_infer.cu:92-94
+ * when the selectors are drawn inside the kernel. */
+void nvw_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* selector of (sample t, utterance b) = top 24 bits of word 0 of Philox(ctr = {t, b, 0, 0},
+ * key = seed) scaled to [0,1): the same layout, [N][B], as the uploaded selector matrix. */
+void nvw_philox_selectors(uint64_t seed, int N, int B, float* sel) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int t = 0; t < N; t++)
+        for (int b = 0; b < B; b++) {
+            uint32_t ctr[4] = {(uint32_t)t, (uint32_t)b, 0u, 0u}, out[4];
+            nvw_philox4x32_10(ctr, key, out);
+            sel[(size_t)t * B + b] = (float)(out[0] >> 8) * (1.0f / 16777216.0f);
+        }
+}
+
+/* pytorch/utils.py:62-70 (mu_law_decode_numpy) followed by pytorch/inference.py:58-60
+ * (MAX_WAV_VALUE * audio, astype('int16')): float64 arithmetic, truncation toward zero, and the
+ * top bin (signal = +1 -> 32768.0) wraps to -32768 exactly as numpy's cast does on x86.
+ * Pinned by tests/golden/mulaw_pcm.npz, generated from the reference's own utils.py. */
+void nvw_mulaw_pcm_table(int A, int16_t* table) {
+    const double mu = (double)A - 1.0;
+    for (int y = 0; y < A; y++) {
+        const double signal = 2.0 * ((double)y / mu) - 1.0;
+        const double magnitude = (1.0 / mu) * (pow(1.0 + mu, fabs(signal)) - 1.0);
+        const double sgn = signal > 0 ? 1.0 : (signal < 0 ? -1.0 : 0.0);
+        const double v = 32768.0 * (sgn * magnitude);
+        table[y] = (int16_t)(int32_t)v;
+    }
+}

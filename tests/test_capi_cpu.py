@@ -87,3 +87,25 @@ def test_nvwavenet_constructor_checks_shapes():
     bad = dict(kw, dilate_weights=[mk(2 * R, R, 3) for _ in range(L)])
     with pytest.raises(AssertionError):
         NVWaveNet(**bad)
+
+
+def test_get_cond_input_matches_torch_modules():
+    """nv_wavenet.get_cond_input restates WaveNet.get_cond_input (pytorch/wavenet.py:190-202) over
+    the module's tensors; compare with the torch modules the reference builds (ConvTranspose1d
+    upsample, 1x1 Conv1d cond_layers) in both output layouts."""
+    import torch
+    from nv_wavenet_amd.nv_wavenet import get_cond_input, column_major
+    torch.manual_seed(0)
+    n_cond, R, L, B, frames, win, stride = 8, 4, 3, 2, 5, 12, 4
+    up = torch.nn.ConvTranspose1d(n_cond, n_cond, win, stride)
+    cl = torch.nn.Conv1d(n_cond, 2 * R * L, 1)
+    feats = torch.randn(B, n_cond, frames)
+    with torch.no_grad():
+        x = up(feats)
+        x = x[:, :, :-(win - stride)]
+        x = cl(x)
+        x = x.view(x.size(0), L, -1, x.size(2)).permute(2, 0, 1, 3)          # 2R x B x L x N
+        got = get_cond_input(feats, up.weight, up.bias, stride, cl.weight, cl.bias, L)
+        got2 = get_cond_input(feats, up.weight, up.bias, stride, cl.weight, cl.bias, L, layout="NLBC")
+    assert got.shape == (2 * R, B, L, frames * stride) and torch.equal(got, x)
+    assert got2.is_contiguous() and torch.equal(got2, column_major(x.contiguous()))

@@ -75,3 +75,29 @@ def test_oracle_partial_batch():
     part = o2.run(s.N, batch_size=5)
     assert np.array_equal(full[:5], part[:5])
     o.close(), o2.close()
+
+
+def test_philox_known_answers():
+    """Random123's kat_vectors for philox4x32-10 pin the generator behind the in-kernel selectors."""
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for ctr, key, want in kat:
+        assert O.philox4x32_10(ctr, key) == want
+    sel = O.philox_selectors(0x299f31d0a4093822, 5, 7)
+    assert sel.shape == (5, 7) and sel.min() >= 0.0 and sel.max() < 1.0
+    w0 = O.philox4x32_10([3, 2, 0, 0], [0xa4093822, 0x299f31d0])[0]
+    assert sel[3, 2] == np.float32((w0 >> 8) / 16777216.0)
+    big = O.philox_selectors(1, 256, 64)
+    assert abs(float(big.mean()) - 0.5) < 0.01 and len(np.unique(big)) > 16000
+
+
+def test_mulaw_pcm_table_matches_reference_python():
+    """tests/golden/mulaw_pcm.npz was produced by the reference's utils.mu_law_decode_numpy +
+    inference.py's int16 cast (tests/golden/make_mulaw_golden.py)."""
+    g = util.load_golden("mulaw_pcm")
+    for A in (256, 512, 1024):
+        assert np.array_equal(O.mulaw_pcm_table(A), g["pcm_%d" % A])

@@ -161,6 +161,52 @@ def test_fp16_teacher_forced_agreement(mode, record_property):
     e.close(), o.close()
 
 
+def _wrapper_model(R, S, A, L, B, N, seed=7):
+    """export_weights()-shaped random tensors (pytorch/wavenet.py:147-188) + a conditioning tensor."""
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    rnd = lambda *s, sc=0.1: (torch.rand(*s, generator=gen) - 0.5) * sc
+    w = dict(embedding_prev=rnd(A, R), embedding_curr=rnd(A, R), conv_out_weight=rnd(A, S, 1),
+             conv_end_weight=rnd(A, A, 1), dilate_weights=[rnd(2 * R, R, 2) for _ in range(L)],
+             dilate_biases=[rnd(2 * R) for _ in range(L)], max_dilation=4,
+             res_weights=[rnd(R, R, 1) for _ in range(L - 1)], res_biases=[rnd(R) for _ in range(L - 1)],
+             skip_weights=[rnd(S, R, 1) for _ in range(L)], skip_biases=[rnd(S) for _ in range(L)],
+             use_embed_tanh=True)
+    cond = rnd(2 * R, B, L, N)
+    dev = {k: ([x.cuda() for x in v] if isinstance(v, list) else v.cuda() if torch.is_tensor(v) else v)
+           for k, v in w.items()}
+    return w, dev, cond
+
+
+def _wrapper_oracle(w, cond, R, S, A, L, B, N, maxD, sel, half=False):
+    """The oracle loaded with the same model the wrapper converts (zero output biases, zero last
+    residual layer: wavenet_infer.cu:75-82, nv_wavenet.py:139-141)."""
+    import ctypes
+    from oracle import oracle as O
+    o = O.Oracle(L, B, N, R, S, A, maxD)
+    rh = (lambda a: a.astype(np.float16).astype(np.float32)) if half else (lambda a: a)
+    f = lambda x: rh(np.ascontiguousarray(x.numpy(), dtype=np.float32))
+    cm = lambda x: f(x.squeeze(-1) if x.dim() == 3 else x).T.copy()
+    lib = o.lib
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    ep, ec = f(w["embedding_prev"]), f(w["embedding_curr"])
+    lib.nvw_oracle_set_embeddings(o.h, fp(ep), fp(ec))
+    zR, zRR = np.zeros(R, np.float32), np.zeros((R, R), np.float32)
+    for l in range(L):
+        dw = w["dilate_weights"][l]
+        a = [cm(dw[:, :, 0]), cm(dw[:, :, 1]), np.ascontiguousarray(w["dilate_biases"][l].numpy()),
+             cm(w["res_weights"][l]) if l < L - 1 else zRR,
+             np.ascontiguousarray(w["res_biases"][l].numpy()) if l < L - 1 else zR,
+             cm(w["skip_weights"][l]), np.ascontiguousarray(w["skip_biases"][l].numpy())]
+        lib.nvw_oracle_set_layer_weights(o.h, l, *[fp(x) for x in a])
+    zA = np.zeros(A, np.float32)
+    wzs, wza = cm(w["conv_out_weight"]), cm(w["conv_end_weight"])
+    lib.nvw_oracle_set_out_weights(o.h, fp(wzs), fp(zA), fp(wza), fp(zA))
+    Lh = rh(np.ascontiguousarray(cond.permute(3, 2, 1, 0).numpy(), dtype=np.float32))
+    o.set_inputs(Lh, sel)
+    return o
+
+
 def test_wavenet_infer_c_abi_and_python_wrapper():
     """The reference's PyTorch path: NVWaveNet(**weights).infer(cond, impl) -> nv_wavenet_ext.infer
     -> wavenet_infer() (pytorch/nv_wavenet.py:172-196, wavenet_infer.cu:105-143). Selectors come
@@ -171,17 +217,7 @@ def test_wavenet_infer_c_abi_and_python_wrapper():
     from nv_wavenet_amd.nv_wavenet import NVWaveNet, Impl
     from oracle import oracle as O
     R, S, A, L, B, N, maxD = 64, 256, 256, 6, 3, 24, 4
-    gen = torch.Generator().manual_seed(7)
-    rnd = lambda *s, sc=0.1: (torch.rand(*s, generator=gen) - 0.5) * sc
-    w = dict(embedding_prev=rnd(A, R), embedding_curr=rnd(A, R), conv_out_weight=rnd(A, S, 1),
-             conv_end_weight=rnd(A, A, 1), dilate_weights=[rnd(2 * R, R, 2) for _ in range(L)],
-             dilate_biases=[rnd(2 * R) for _ in range(L)], max_dilation=maxD,
-             res_weights=[rnd(R, R, 1) for _ in range(L - 1)], res_biases=[rnd(R) for _ in range(L - 1)],
-             skip_weights=[rnd(S, R, 1) for _ in range(L)], skip_biases=[rnd(S) for _ in range(L)],
-             use_embed_tanh=True)
-    cond = rnd(2 * R, B, L, N)
-    dev = {k: ([x.cuda() for x in v] if isinstance(v, list) else v.cuda() if torch.is_tensor(v) else v)
-           for k, v in w.items()}
+    w, dev, cond = _wrapper_model(R, S, A, L, B, N)
     libc = ctypes.CDLL("libc.so.6")
     model, cond_dev = NVWaveNet(**dev), cond.cuda()
     # the HIP runtime draws from libc rand() when it first loads a code object, so warm every
@@ -196,25 +232,90 @@ def test_wavenet_infer_c_abi_and_python_wrapper():
     sel = np.zeros((N, B), dtype=np.float32)
     O._lib("oracle").nvw_randomize(sel.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), B, N,
                                    ctypes.c_float(0.5), ctypes.c_float(1.0))
-    o = O.Oracle(L, B, N, R, S, A, maxD)
-    f = lambda x: np.ascontiguousarray(x.numpy(), dtype=np.float32)
-    cm = lambda x: f(x.squeeze(-1) if x.dim() == 3 else x).T.copy()
-    lib = o.lib
-    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-    ep, ec = f(w["embedding_prev"]), f(w["embedding_curr"])
-    lib.nvw_oracle_set_embeddings(o.h, fp(ep), fp(ec))
-    zR, zRR = np.zeros(R, np.float32), np.zeros((R, R), np.float32)
-    for l in range(L):
-        dw = w["dilate_weights"][l]
-        a = [cm(dw[:, :, 0]), cm(dw[:, :, 1]), f(w["dilate_biases"][l]),
-             cm(w["res_weights"][l]) if l < L - 1 else zRR, f(w["res_biases"][l]) if l < L - 1 else zR,
-             cm(w["skip_weights"][l]), f(w["skip_biases"][l])]
-        lib.nvw_oracle_set_layer_weights(o.h, l, *[fp(x) for x in a])
-    zA = np.zeros(A, np.float32)
-    wzs, wza = cm(w["conv_out_weight"]), cm(w["conv_end_weight"])
-    lib.nvw_oracle_set_out_weights(o.h, fp(wzs), fp(zA), fp(wza), fp(zA))
-    Lh = np.ascontiguousarray(cond.permute(3, 2, 1, 0).numpy(), dtype=np.float32)
-    o.set_inputs(Lh, sel)
-    y_ref = o.run(N)
-    assert np.array_equal(y, y_ref)
+    o = _wrapper_oracle(w, cond, R, S, A, L, B, N, maxD, sel)
+    assert np.array_equal(y, o.run(N))
     o.close()
+
+
+def test_persistent_python_wrapper_seeded_audio():
+    """NVWaveNetEngine keeps the engine (and the uploaded weights) alive across
+    infer() calls, takes R/S/A from the tensors (here an instantiation wavenet_infer() does not
+    offer), accepts the conditioning already in the engine's layout on the device, draws selectors
+    in-kernel from a seed and returns int16 audio. fp32: indices identical to the oracle's under
+    the same Philox selectors, on every call."""
+    import torch
+    from nv_wavenet_amd.nv_wavenet import NVWaveNetEngine, Impl
+    R, S, A, L, B, N, maxD = 64, 128, 256, 6, 5, 40, 4
+    w, dev, cond = _wrapper_model(R, S, A, L, B, N, seed=11)
+    table = util.load_golden("mulaw_pcm")["pcm_%d" % A]
+    model = NVWaveNetEngine(**dev, precision=32)
+    cond_nlbc = cond.permute(3, 2, 1, 0).contiguous().cuda()
+    for call, seed in enumerate((5, 5, 99)):
+        o = _wrapper_oracle(w, cond, R, S, A, L, B, N, maxD, util.O.philox_selectors(seed, N, B))
+        y_ref = o.run(N)
+        o.close()
+        if call == 0:
+            y, audio = model.infer(cond.cuda(), Impl.MANYBLOCK, seed=seed, return_audio=True)
+        else:
+            y, audio = model.infer(cond_nlbc, Impl.MANYBLOCK, seed=seed, return_audio=True, layout="NLBC")
+        assert np.array_equal(y.cpu().numpy(), y_ref), "call %d" % call
+        assert np.array_equal(audio.cpu().numpy(), table[y_ref])
+    assert len(model._engines) == 1, "the engine must be reused across calls"
+    # torch-drawn selectors (no seed): plausible output, engine still reused
+    y = model.infer(cond_nlbc, Impl.MANYBLOCK, layout="NLBC", generator=torch.Generator(device="cuda").manual_seed(3))
+    assert y.shape == (B, N) and int(y.min()) >= 0 and int(y.max()) < A and len(model._engines) == 1
+    model.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_in_kernel_selectors_and_pcm_out(mode):
+    """SURVEY.md 8f rank 2. With setSelectorSeed the engine draws its selectors in-kernel
+    (Philox4x32-10); the oracle fed nvw_philox_selectors(seed) must produce the same fp32 indices,
+    bit for bit, with no selector matrix uploaded. setAudioOut adds int16 PCM = the reference's
+    mu_law_decode_numpy + int16 cast (fixture tests/golden/mulaw_pcm.npz) of those indices, through
+    run() and through run_chunks()."""
+    case = cases.BY_NAME["C3_R64S256A256_L20_B21"]      # ragged batch, 2 tiles
+    s = case.shape
+    seed = 0x1234ABCD5678EF01
+    t = util.gen_inputs(case)
+    o = util.make_oracle(case, t)
+    sel = util.O.philox_selectors(seed, s.N, s.B)
+    o.set_inputs(t.Lh, sel)
+    y_ref = o.run(s.N)
+    table = util.load_golden("mulaw_pcm")["pcm_%d" % s.A]
+    assert len(np.unique(y_ref)) > 8
+
+    e = util.make_engine(case, t, precision=32, mode=mode)   # uploads t.sel, which must NOT be used
+    e.setConditioning(t.Lh)
+    e.setSelectorSeed(seed)
+    y = np.full((s.B, s.N), -1, dtype=np.int32)
+    pcm = np.full((s.B, s.N), 7, dtype=np.int16)
+    e.setAudioOut(pcm)
+    assert e.run(s.N, s.B, y, 1, False)
+    e.synchronize()
+    assert np.array_equal(y, y_ref), "in-kernel Philox selectors differ from the oracle's"
+    assert np.array_equal(pcm, table[y_ref])
+
+    # chunked: the consumer sees finished PCM for its chunk
+    e.setConditioning(t.Lh)
+    y2 = np.full((s.B, s.N), -1, dtype=np.int32)
+    pcm2 = np.zeros((s.B, s.N), dtype=np.int16)
+    e.setAudioOut(pcm2)
+    seen = []
+
+    def consume(yo, first, count):
+        seen.append(np.array_equal(pcm2[:, first:first + count], table[y_ref[:, first:first + count]]))
+    assert e.run_chunks(16, consume, s.N, s.B, y2, 1)
+    e.synchronize()
+    assert seen and all(seen)
+    assert np.array_equal(y2, y_ref) and np.array_equal(pcm2, table[y_ref])
+
+    # back to the uploaded table
+    e.setAudioOut(None)
+    e.setInputs(t.Lh, t.sel)
+    o.set_inputs(t.Lh, t.sel)
+    y3 = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, s.B, y3, 1, False)
+    e.synchronize()
+    assert np.array_equal(y3, o.run(s.N))
+    e.close(), o.close()
