@@ -170,7 +170,7 @@ def cpu_baseline(w, budget_s=20.0):
     cores = min(cores, 64)
     if cores > 1:
         # separate interpreters (no torch, no HIP): a fork of this process would carry the GPU runtime
-        n2 = max(8, n // 2)
+        n2 = max(8, n // 4)
         t0 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n2), "--cpu-seed", str(i)],
                                   stdout=subprocess.PIPE, cwd=ROOT) for i in range(cores)]

@@ -100,9 +100,14 @@ struct Cfg {
     // per-wave fragment stream of the head: zs | za
     static constexpr int FW_ZS = ATW * KF_S, FW_ZA = ATW * KF_A;
     static constexpr int FHW = FW_ZS + FW_ZA;
-    // depth of the per-wave weight prefetch ring.  Deeper is NOT better: measured on MI355X, 18 in
-    // flight per wave is 12% slower than 9 (the wave's VMEM queue fills and instruction issue stalls).
-    static constexpr int PF = pick_pf(FLW, 12);
+    // depth of the per-wave weight prefetch ring.  Measured on MI355X (C3 fp16, us per sample at
+    // batch 16 / 4096): depth 3: 26.2 / 38.8, 6: 24.5 / 33.3, 9: 22.7 / 29.9, 18: 27.4 / 35.6; a
+    // whole-layer ring refilled at points spread over the layer body instead of at take time: 23.0 /
+    // 28.8 (no better than 9, and it spills with two tiles per workgroup).
+#ifndef WN_PFMAX
+#define WN_PFMAX 12
+#endif
+    static constexpr int PF = pick_pf(FLW, WN_PFMAX);
     static_assert(FLW % PF == 0 && PF <= FW_ZS, "prefetch ring must divide the layer stream");
     // The head's weights (FHW fragments per wave) stay RESIDENT in registers for the whole launch
     // when they fit the otherwise idle accumulator half of the register file (4 regs/fragment):
@@ -112,9 +117,17 @@ struct Cfg {
 #ifdef WN_ABL_NOHEADRES
     static constexpr int HR = 0;
 #else
+    // Register budget of the resident head.  Measured (C3 fp16): keeping Wzs resident as well (256
+    // registers) buys nothing over Wza alone (128) and costs spills once the layer loop is unrolled.
+#ifndef WN_HEADREGS
+#define WN_HEADREGS 128
+#endif
+#ifndef WN_HEADREGS2
+#define WN_HEADREGS2 128     // two tiles per workgroup
+#endif
     static constexpr int HR = !F16 ? 0
-                              : BT == 1 ? (FHW * 4 <= 256 ? FHW : (FW_ZA * 4 <= 256 ? FW_ZA : 0))
-                                        : (FW_ZA * 4 <= 128 ? FW_ZA : 0);
+                              : BT == 1 ? (FHW * 4 <= WN_HEADREGS ? FHW : (FW_ZA * 4 <= WN_HEADREGS ? FW_ZA : 0))
+                                        : (FW_ZA * 4 <= WN_HEADREGS2 ? FW_ZA : 0);
 #endif
     static constexpr int HS = FHW - HR;
     static constexpr bool HEADRES = HS == 0;              // the stream cycles over the layers only
@@ -573,7 +586,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     // Each wave re-loads only the ring fragments it stored itself (k % NW == w) and the waves share
     // them through LDS: 1/NW of the ring loads per wave instead of all of them.
     constexpr int XPW = C::XPW;
-    frag xpA[BT][XPW], xpB[BT][XPW];            // next layer / the one after
+    // Two register sets used alternately by layer parity (no rotation copies: a copy would force
+    // the load issued one layer earlier to have landed, i.e. halve the prefetch distance).
+    frag xpA[BT][XPW], xpB[BT][XPW];            // layers of even / odd parity
     frag cdA[BT][C::COND_FR], cdB[BT][C::COND_FR];
     // per-(sample,layer) strides in bytes; everything here is wave-uniform (SALU)
     const size_t condStride = (size_t)p.tiles * NW * C::COND_FR * 1024;            // one (sample,layer) row
@@ -616,17 +631,17 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     };
     prefetch(p.initSample, 0, dil_first(), xpA, cdA);
     prefetch(p.initSample, 1, dil_next(dil_first(), p.maxDilation, false), xpB, cdB);
-    // publish this wave's fragments of the NEXT layer's dilated tap (held in xpA) to LDS
-    auto publish_xp = [&]() {
+    // publish this wave's fragments of the NEXT layer's dilated tap to LDS
+    auto publish_xp = [&](const frag (&xpN)[BT][XPW]) {
 #pragma unroll
         for (int bt = 0; bt < BT; bt++)
 #pragma unroll
             for (int i = 0; i < XPW; i++) {
                 const int k = w + NW * i;
-                if (k < KF_R) *(frag*)(xpbuf + ((bt * KF_R + k) * 64 + lane) * 16) = xpA[bt][i];
+                if (k < KF_R) *(frag*)(xpbuf + ((bt * KF_R + k) * 64 + lane) * 16) = xpN[bt][i];
             }
     };
-    publish_xp();   // layer 0 of the first sample (ordered by the embedding barrier)
+    publish_xp(xpA);   // layer 0 of the first sample (ordered by the embedding barrier)
 
     __syncthreads();   // bias table visible
 
@@ -646,7 +661,11 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #endif
     const int tEnd = p.initSample + p.count;
     for (int t = p.initSample; t < tEnd; t++) {
+#ifdef WN_ABL_NODUMP
+        constexpr bool dumpNow = false;
+#else
         const bool dumpNow = p.dump && (t == tEnd - 1);
+#endif
 
         // selector of the utterance this lane serves in the softmax
         float selv[BT];
@@ -695,7 +714,11 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         // fragments come back from LDS; the weight stream order [prev|cur|res|skip] per layer is
         // consumed as  prev(0) cur(0) res(0) | skip(0) prev(1) cur(1) res(1) | ... | skip(L-1).
         frag hb[BT][KF_R];
-        auto layer = [&](auto withSkip, const int l, const Dil dl, const Dil dl2) {
+        // (xpC, cdC): register set of this layer's parity -- its conditioning is consumed by the gate,
+        // its dilated tap was published at the end of the previous layer, and the prefetch for layer
+        // l+2 refills it; xpN: the other set, holding the tap of layer l+1 (published at the end).
+        auto layer = [&](auto withSkip, const int l, const Dil dl, const Dil dl2, frag (&xpC)[BT][XPW],
+                         frag (&cdC)[BT][C::COND_FR], const frag (&xpN)[BT][XPW]) {
             constexpr bool SKIP = decltype(withSkip)::value;
             // fragment positions are relative to the start of layer l-1 (SKIP) / layer l
             const char* wl = wbase + (size_t)(SKIP ? l - 1 : l) * FLW * 1024;
@@ -738,7 +761,6 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             // dilated tap: x_l[t-d] was prefetched and published to LDS by its owners during the
             // previous layer; zero before the start (reference :287)
             frag xp[BT][KF_R];
-            frag cd[BT][C::COND_FR];
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) {
                 lds_get_frags<F16, KF_R>(xpbuf + bt * KF_R * 1024, lane, xp[bt]);
@@ -748,13 +770,6 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                         for (int e = 0; e < P::EPL; e++) xp[bt][k][e] = (elem)0.f;
                     }
-                }
-#pragma unroll
-                for (int i = 0; i < XPW; i++) xpA[bt][i] = xpB[bt][i];
-#pragma unroll
-                for (int k = 0; k < C::COND_FR; k++) {
-                    cd[bt][k] = cdA[bt][k];
-                    cdA[bt][k] = cdB[bt][k];
                 }
             }
             WN_TMARK(1)
@@ -773,7 +788,14 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int k = 0; k < C::COND_FR; k++)
 #pragma unroll
-                    for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cd[bt][k][e];
+                    for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cdC[bt][k][e];
+#ifndef WN_PREFETCH_LATE
+            // VMEM returns in order: the first weight fragment requested AFTER these HBM loads is taken
+            // by the next layer's GEMMs, so issuing them here, ahead of the take-free gate / exchange
+            // phases, gives them the longest time to land before anything queues behind them
+            prefetch(t, l + 2, dl2, xpC, cdC);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 
             // gate -> h tiles of this wave -> LDS
 #pragma unroll
@@ -797,11 +819,14 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int i = 0; i < HTW; i++)
                     xa[bt][i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[bt][i];
-            prefetch(t, l + 2, dl2, xpB, cdB);
+#ifdef WN_PREFETCH_LATE
+            prefetch(t, l + 2, dl2, xpC, cdC);
+#endif
             WN_TMARK(3)
 
             // residual: x <- Wres h + Bres + x  (this wave's tiles) -> LDS
             gemm<F16, PF, 0, BT, HTW, KF_R>(ws, OFS + C::O_RES, wl, wl, laneOff, xa, hb, wrapAt, wrapDelta);
+
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
@@ -820,7 +845,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 }
             }
             WN_TMARK(6)
-            publish_xp();   // dilated tap of layer l+1 (layer 0 of the next sample after the last layer)
+            publish_xp(xpN);   // dilated tap of layer l+1 (layer 0 of the next sample after the last layer)
             wg_barrier();   // x complete
             WN_TMARK(7)
         };
@@ -829,12 +854,40 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             Dil d1 = dil_next(d0, p.maxDilation, 1 >= L);
             Dil d2 = dil_next(d1, p.maxDilation, 2 >= L && 2 - L == 0);
             // dK = schedule entry of layer (l+K) mod L, (l+2 may wrap into the next sample)
-            layer(std::false_type{}, 0, d0, d2);
-            for (int l = 1; l < L; l++) {
+            layer(std::false_type{}, 0, d0, d2, xpA, cdA, xpB);
+            auto step = [&](const int l) {
                 d0 = d1;
                 d1 = d2;
                 d2 = dil_next(d1, p.maxDilation, l + 2 == L);   // layer l+2 == L is layer 0 of the next sample
-                layer(std::true_type{}, l, d0, d2);
+            };
+            int l = 1;
+            for (; l + 1 < L; l += 2) {
+                step(l);
+                layer(std::true_type{}, l, d0, d2, xpB, cdB, xpA);
+                step(l + 1);
+                layer(std::true_type{}, l + 1, d0, d2, xpA, cdA, xpB);
+            }
+            if (l < L) {
+                step(l);
+                layer(std::true_type{}, l, d0, d2, xpB, cdB, xpA);
+            }
+            if (L & 1) {
+                // odd layer count: layer 0 of the next sample was prefetched into the odd set
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++) {
+#pragma unroll
+                    for (int i = 0; i < XPW; i++) {
+                        const frag tmp = xpA[bt][i];
+                        xpA[bt][i] = xpB[bt][i];
+                        xpB[bt][i] = tmp;
+                    }
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++) {
+                        const frag tmp = cdA[bt][k];
+                        cdA[bt][k] = cdB[bt][k];
+                        cdB[bt][k] = tmp;
+                    }
+                }
             }
         }
         // skip GEMM of the last layer
