@@ -316,9 +316,11 @@ def main():
         units = B * N                                   # utterance-samples per launch
         flops = units * FLOPS
         tiles = (B + 15) // 16
-        stream_mode = tiles > ncu                               # engine's choice (nv_wavenet.hpp)
-        passes = (tiles + 3) // 4 if stream_mode else tiles     # workgroups (weight-stream passes) per sample
-        kname = "wn::wavenet_stream<fp16,64,256,256>" if stream_mode else "wn::wavenet_wg<fp16,64,256,256,BT=1>"
+        stream_mode = tiles > 2 * ncu                           # engine's choice (nv_wavenet.hpp)
+        bt = 2 if tiles > ncu else 1                            # tiles per workgroup of the latency kernel
+        # workgroups (weight-stream passes) per sample
+        passes = (tiles + 3) // 4 if stream_mode else (tiles + bt - 1) // bt
+        kname = "wn::wavenet_stream<fp16,64,256,256>" if stream_mode else "wn::wavenet_wg<fp16,64,256,256,BT=%d>" % bt
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tf):
@@ -334,7 +336,7 @@ def main():
                         hbm=dict(achieved=units * HBM_BYTES / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"),
                         l2_weight_stream=dict(achieved=passes * N * WEIGHT_BYTES / (kern_ms * 1e-3) / 1e9,
                                               peak=L2_PEAK_GBS, unit="GB/s"),
-                        lds=dict(achieved=passes * N * lds_bytes_per_sample(stream_mode) / (kern_ms * 1e-3) / 1e9,
+                        lds=dict(achieved=passes * N * lds_bytes_per_sample(stream_mode, 1 if stream_mode else bt) / (kern_ms * 1e-3) / 1e9,
                                  peak=LDS_PEAK_GBS, unit="GB/s"))
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         roofline["hbm"]["frac"] = roofline["hbm"]["achieved"] / HBM_PEAK_GBS

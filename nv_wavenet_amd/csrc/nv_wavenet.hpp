@@ -140,27 +140,36 @@ protected:
     template <int BT> int embTables() const {
         return ldsNeed<BT>(m_numLayers, 2) <= kLdsMax ? 2 : ldsNeed<BT>(m_numLayers, 1) <= kLdsMax ? 1 : 0;
     }
-    template <int BT, bool EMB> bool launchK(wn::Params& p, int tiles, int nEmb, hipStream_t stream) {
+    // DUMP = false (no activation dump code at all) exists for the fp16 engine, the production path;
+    // the fp32 engine is the parity mode and always carries the dump
+    template <int BT, bool EMB, bool DUMP> bool launchK(wn::Params& p, int tiles, int nEmb, hipStream_t stream) {
         using CB = wn::Cfg<F16, R, S, A, BT>;
         const int grid = (tiles + BT - 1) / BT;
         p.embLds = nEmb;
-        hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB>), dim3(grid), dim3(CB::THREADS),
+        hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP>), dim3(grid), dim3(CB::THREADS),
                            ldsNeed<BT>(m_numLayers, nEmb), stream, p);
         return hipGetLastError() == hipSuccess;
     }
     template <int BT> bool launch(wn::Params& p, int tiles, hipStream_t stream) {
         const int nEmb = embTables<BT>();
-        return nEmb ? launchK<BT, true>(p, tiles, nEmb, stream) : launchK<BT, false>(p, tiles, 0, stream);
+        if constexpr (F16) {
+            if (!p.dump) return nEmb ? launchK<BT, true, false>(p, tiles, nEmb, stream) : launchK<BT, false, false>(p, tiles, 0, stream);
+        }
+        return nEmb ? launchK<BT, true, true>(p, tiles, nEmb, stream) : launchK<BT, false, true>(p, tiles, 0, stream);
     }
-    template <int BT, bool EMB> void allowLdsK() {
+    template <int BT, bool EMB, bool DUMP> void allowLdsK() {
         const size_t need = ldsNeed<BT>(m_numLayers, EMB ? embTables<BT>() : 0);
         if (need <= kLdsMax)
-            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB>,
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
     template <int BT> void allowLds() {
-        allowLdsK<BT, false>();
-        allowLdsK<BT, true>();
+        allowLdsK<BT, false, true>();
+        allowLdsK<BT, true, true>();
+        if constexpr (F16) {
+            allowLdsK<BT, false, false>();
+            allowLdsK<BT, true, false>();
+        }
     }
     float* headBias() { return m_bias + (size_t)m_numLayers * C::BIAS_L; }
 
@@ -194,15 +203,16 @@ public:
         }
         m_ringSlots = slots;
 
-        // kernel organisation: with more tiles than CUs every SIMD gets its own tile and the weights
-        // are streamed once per CU through an LDS ring (wn_stream.hpp); otherwise one tile is split
-        // over the 4 SIMDs of a CU (wn_kernels.hpp).  NVW_MODE=stream|wg overrides (experiments).
+        // kernel organisation: up to two tiles per CU run in the latency kernel (wn_kernels.hpp: one or
+        // two tiles split over the 4 SIMDs of a CU); beyond that every SIMD gets its own tile and the
+        // weights are streamed once per CU through an LDS ring (wn_stream.hpp).  NVW_MODE=stream|wg
+        // overrides (tests, experiments).
         {
             const size_t biasBytes = ((size_t)numLayers * SC::BIAS_L + 2 * A) * sizeof(float);
             long ns = ((long)kLdsMax - (long)biasBytes) / ((long)SC::CH * 1024);
             m_streamNS = (int)(ns > 6 ? 6 : ns);
             const char* mode = getenv("NVW_MODE");
-            m_streamMode = (batchSize + 15) / 16 > m_numCUs;
+            m_streamMode = (batchSize + 15) / 16 > 2 * m_numCUs;   // up to two tiles per CU: the latency kernel
             if (mode && !strcmp(mode, "stream")) m_streamMode = true;
             if (mode && !strcmp(mode, "wg")) m_streamMode = false;
             if (m_streamNS < SC::MIN_NS) m_streamMode = false;

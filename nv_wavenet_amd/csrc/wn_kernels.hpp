@@ -400,6 +400,13 @@ WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const char* 
     const char* src = (WRAP > 0 && nidx >= WRAP) ? wrapBase + (size_t)(nidx - WRAP) * 1024 : base + (size_t)nidx * 1024;
     if (nidx >= rtWrapAt) src += rtWrapDelta;
     ws.buf[idx % PF] = *(const frag*)(src + laneOff);
+#ifndef WN_FREE_REFILL
+    // The refill stays where the ring discipline puts it.  Left to the scheduler the loads get
+    // clustered and re-ordered, and now and then a fragment that is needed next ends up among the
+    // youngest requests (a near-drain of the queue): pinned, C3 fp16 runs 39.0 instead of 42.0 us per
+    // sample with two tiles per workgroup at batch 8192.
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #else
     (void)nidx; (void)base; (void)wrapBase; (void)laneOff; (void)rtWrapAt; (void)rtWrapDelta;
 #endif
@@ -475,7 +482,10 @@ WN_DEV void gemm_res(const typename Prec<F16>::frag (&wres)[NFR], int pos0, floa
 // EMBLDS: both embedding tables are copied to LDS at launch, so the gather that follows every
 // sample pick (on the critical path) is a ds_read instead of a global load queued behind the
 // in-flight weight prefetch.
-template <bool F16, int R, int S, int A, int BT, bool EMBLDS>
+// DUMP: the variant that can write the activation dump of the launch's last sample (getXtOut ...).
+// Production launches (dumpActivations = false) use DUMP = false: even as a never-taken branch the
+// dump costs accumulator read-outs in every layer (35.6 vs 39.0 us per sample at batch 8192).
+template <bool F16, int R, int S, int A, int BT, bool EMBLDS, bool DUMP = true>
 __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_wg(const Params p) {
     using C = Cfg<F16, R, S, A, BT>;
     using P = Prec<F16>;
@@ -661,11 +671,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #endif
     const int tEnd = p.initSample + p.count;
     for (int t = p.initSample; t < tEnd; t++) {
-#ifdef WN_ABL_NODUMP
-        constexpr bool dumpNow = false;
-#else
-        const bool dumpNow = p.dump && (t == tEnd - 1);
-#endif
+        const bool dumpNow = DUMP && p.dump && (t == tEnd - 1);
 
         // selector of the utterance this lane serves in the softmax
         float selv[BT];

@@ -125,6 +125,13 @@ def test_fp16_engine_against_fp32_oracle(name, mode):
     assert np.all(za_err <= 2e-2 * np.abs(ref["Za"][ok]) + 2e-3), "logit error %g" % za_err.max()
     assert np.all(np.abs(got["P"][ok] / ref["P"][ok] - 1) <= 2e-2)
     assert np.all(np.abs(got["Xout"][:, ok] - ref["Xout"][:, ok]) <= 2e-2 * np.abs(ref["Xout"][:, ok]) + 2e-3)
+    # the production launch (dumpActivations = false) runs a kernel variant without any dump code:
+    # it must generate the same samples from the same inputs
+    e.setInputs(t.Lh, t.sel)
+    y2 = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, s.B, y2, _bspb(s.B), False)
+    e.synchronize()
+    assert np.array_equal(y2, y), "dump and no-dump kernel variants disagree"
     e.close(), o.close()
 
 
