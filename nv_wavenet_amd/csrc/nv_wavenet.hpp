@@ -59,6 +59,7 @@ protected:
     Implementation m_implementation;
     int m_numLayers, m_maxBatch, m_maxSamples, m_maxDilation, m_tiles, m_numCUs;
     bool m_streamMode;   // true: wn::wavenet_stream (>= 1 tile per SIMD), false: wn::wavenet_wg (lowest latency)
+    int m_forceBt;       // tiles per workgroup of wn::wavenet_wg forced by NVW_MODE=wg1|wg2 (0: by batch size)
     int m_streamNS;      // LDS ring slots of the throughput kernel
     bool m_tanhEmbed;
     int m_num_samples_per_chunk;
@@ -213,8 +214,13 @@ public:
             m_streamNS = (int)(ns > 6 ? 6 : ns);
             const char* mode = getenv("NVW_MODE");
             m_streamMode = (batchSize + 15) / 16 > 2 * m_numCUs;   // up to two tiles per CU: the latency kernel
+            m_forceBt = 0;
             if (mode && !strcmp(mode, "stream")) m_streamMode = true;
-            if (mode && !strcmp(mode, "wg")) m_streamMode = false;
+            if (mode && !strncmp(mode, "wg", 2)) {
+                m_streamMode = false;
+                m_forceBt = mode[2] == '1' ? 1 : mode[2] == '2' ? 2 : 0;
+            }
+            if (const char* fb = getenv("NVW_FORCE_BT")) m_forceBt = atoi(fb);   // experiments
             if (m_streamNS < SC::MIN_NS) m_streamMode = false;
         }
         const size_t wElems = m_streamMode ? SC::streamFrags(numLayers) * SC::FRAG_ELEMS
@@ -531,8 +537,7 @@ public:
         // two tiles per workgroup share one pass over the weights beyond that
         const int tiles = (batch_size + 15) / 16;
         bool result;
-        const char* forceBt = getenv("NVW_FORCE_BT");   // experiments only
-        const bool two = forceBt ? (atoi(forceBt) == 2) : (tiles > m_numCUs);
+        const bool two = m_forceBt ? m_forceBt == 2 : tiles > m_numCUs;
         if (m_streamMode) {
             hipLaunchKernelGGL((wn::wavenet_stream<F16, R, S, A>), dim3((tiles + 3) / 4), dim3(512),
                                SC::ldsBytes(m_numLayers, m_streamNS), stream, p, m_streamNS);

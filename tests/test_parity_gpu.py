@@ -18,7 +18,10 @@ def _bspb(B):
     return 4 if B % 4 == 0 else 2 if B % 2 == 0 else 1  # nv_wavenet_test.cu:247
 
 
-MODES = ["wg", "stream"]   # the two kernel organisations (wn_kernels.hpp / wn_stream.hpp)
+# the kernel organisations: the latency kernel with one / two tiles of 16 utterances per workgroup
+# (wn_kernels.hpp; the engine picks two beyond one tile per CU) and the loader/consumer kernel
+# (wn_stream.hpp; beyond two tiles per CU)
+MODES = ["wg", "wg2", "stream"]
 
 
 @pytest.mark.parametrize("mode", MODES)

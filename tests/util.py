@@ -32,8 +32,8 @@ def make_oracle(case, t):
 
 def make_engine(case, t, precision=32, impl=None, device_ptrs=False, mode=None):
     """Build the HIP engine through the C ABI and upload the model + inputs.
-    mode: None = the engine's own choice by batch size; "wg" / "stream" force one of the two kernel
-    organisations (NVW_MODE is read by the engine at construction)."""
+    mode: None = the engine's own choice by batch size; "wg" / "wg2" / "stream" force a kernel
+    organisation (NVW_MODE is read by the engine at construction)."""
     from nv_wavenet_amd import WavenetEngine
     s = case.shape
     old = os.environ.get("NVW_MODE")
