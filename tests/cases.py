@@ -43,6 +43,10 @@ EXTRA_CASES = [
     Case("C4_R128S256A256_L30_B8", 50, [], Shape(128, 256, 256, 30, 8, 48, 16), 2, 1, 20),
     # R=256: only the reference's perf harness instantiates it (nv_wavenet_perf.cu:156-166)
     Case("R256S256A256_L6_B5", 90, [], Shape(256, 256, 256, 6, 5, 24, 8), 3, 1, 10),
+    # odd layer counts: the engine alternates two prefetch register sets by layer parity, and an odd
+    # count flips the parity from one sample to the next
+    Case("R64S128A256_L7_B19_oddL", 91, [], Shape(64, 128, 256, 7, 19, 40, 4), 1, 1, 13),
+    Case("R64S256A256_L3_B16_oddL", 92, [], Shape(64, 256, 256, 3, 16, 24, 2), 3, 1, 24),
 ]
 
 ALL_CASES = REF_CASES + EXTRA_CASES

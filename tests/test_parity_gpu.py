@@ -104,7 +104,8 @@ def test_run_equals_run_chunks_and_partial_batch():
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["R64S256A256_impl3", "R64S128A256_impl1", "R32S128A256_impl1", "R128S256A256_impl3",
-                                  "R64S128A512_impl3", "R128S256A1024_impl3", "R256S256A256_L6_B5"])
+                                  "R64S128A512_impl3", "R128S256A1024_impl3", "R256S256A256_L6_B5",
+                                  "R64S128A256_L7_B19_oddL", "R64S256A256_L3_B16_oddL"])
 def test_fp16_engine_against_fp32_oracle(name, mode):
     """fp16 parity is unpinned by the reference (no test runs half). Stated tolerance: with every
     weight / bias / embedding / conditioning value rounded to fp16 and fed to BOTH sides, the fp16
