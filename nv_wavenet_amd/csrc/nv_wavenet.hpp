@@ -271,10 +271,15 @@ public:
         }
         allowLds<1>();
         allowLds<2>();
-        if (m_streamMode)
-            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_stream<F16, R, S, A>,
+        if (m_streamMode) {
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_stream<F16, R, S, A, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)SC::ldsBytes(numLayers, m_streamNS)));
+            if constexpr (F16)
+                gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_stream<F16, R, S, A, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)SC::ldsBytes(numLayers, m_streamNS)));
+        }
         gpuErrChk(hipDeviceSynchronize());
     }
 
@@ -539,8 +544,16 @@ public:
         bool result;
         const bool two = m_forceBt ? m_forceBt == 2 : tiles > m_numCUs;
         if (m_streamMode) {
-            hipLaunchKernelGGL((wn::wavenet_stream<F16, R, S, A>), dim3((tiles + 3) / 4), dim3(512),
-                               SC::ldsBytes(m_numLayers, m_streamNS), stream, p, m_streamNS);
+            bool noDump = false;
+            if constexpr (F16) noDump = !p.dump;
+            if (noDump) {
+                if constexpr (F16)
+                    hipLaunchKernelGGL((wn::wavenet_stream<F16, R, S, A, false>), dim3((tiles + 3) / 4), dim3(512),
+                                       SC::ldsBytes(m_numLayers, m_streamNS), stream, p, m_streamNS);
+            } else {
+                hipLaunchKernelGGL((wn::wavenet_stream<F16, R, S, A, true>), dim3((tiles + 3) / 4), dim3(512),
+                                   SC::ldsBytes(m_numLayers, m_streamNS), stream, p, m_streamNS);
+            }
             result = hipGetLastError() == hipSuccess;
         } else if (two && ldsFits<2>()) result = launch<2>(p, tiles, stream);
         else result = launch<1>(p, tiles, stream);

@@ -93,7 +93,9 @@ template <int KT> WN_DEV void to_bfrags(const floatx4 (&t)[KT], floatx4 (&b)[KT]
     for (int k = 0; k < KT; k++) b[k] = t[k];
 }
 
-template <bool F16, int R, int S, int A>
+// DUMP: see wn::wavenet_wg -- production launches use the variant without any activation-dump code
+// (57.5 instead of 62.3 us per sample at batch 16384).
+template <bool F16, int R, int S, int A, bool DUMP = true>
 __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const int NS) {
     using C = SCfg<F16, R, S, A>;
     using P = Prec<F16>;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
 #endif
     const int tEnd = p.initSample + p.count;
     for (int t = p.initSample; t < tEnd; t++) {
-        const bool dumpNow = p.dump && (t == tEnd - 1);
+        const bool dumpNow = DUMP && p.dump && (t == tEnd - 1);
         const float selv = p.useRng ? philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)bc)
                                     : p.sel[(size_t)t * p.maxBatch + bc];
         WN_SMARK(11)
