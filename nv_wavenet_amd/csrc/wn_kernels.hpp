@@ -27,9 +27,13 @@
 //     in-flight weight prefetch is never drained).
 //   * Biases live in LDS for the whole launch and initialise the MFMA accumulators.
 //   * The dilated history x_l[t-d_l] is a ring of exactly d_l slots per layer in global memory
-//     (B-fragment order, 1-KiB coalesced rows, prefetched one layer ahead): sum(d_l)*R*16
-//     elements per tile instead of the reference's (maxDilation+1)*(L+1) planes
-//     (nv_wavenet.cuh:334-335).
+//     (B-fragment order, 1-KiB coalesced rows): sum(d_l)*R*16 elements per tile instead of the
+//     reference's (maxDilation+1)*(L+1) planes (nv_wavenet.cuh:334-335).
+//   * VMEM returns in order per wave.  Everything the weight stream could delay is kept off that
+//     path (dilation schedule in scalar arithmetic, biases / embeddings in LDS), and the slow HBM
+//     loads (conditioning, dilated tap) that could delay the weight stream are requested two layers
+//     ahead, into register sets alternating by layer parity, at the point of the layer where the
+//     longest take-free stretch begins; every refill of the weight ring is pinned to its take.
 //   * softmax + inverse-CDF pick: logits go through LDS once; 16 lanes per utterance, reductions
 //     with cross-lane shuffles inside a 16-lane row.
 //
