@@ -330,3 +330,59 @@ def test_in_kernel_selectors_and_pcm_out(mode):
     e.synchronize()
     assert np.array_equal(y3, o.run(s.N))
     e.close(), o.close()
+
+
+@pytest.mark.parametrize("B", [4112, 8208])
+def test_full_chip_batches_by_replication(B):
+    """Size-independent property at the batch sizes where the engine changes organisation by itself
+    (257 tiles: two tiles per workgroup; 513 tiles: loader/consumer kernel on a 256-CU GPU): utterances
+    are independent, so a batch that repeats the 19 utterances of a small case cyclically must repeat
+    that case's fp32 samples, which are pinned to the oracle and the reference fixture."""
+    case = cases.BY_NAME["R64S128A256_L7_B19_oddL"]
+    s = case.shape
+    g = util.load_golden(case.name)
+    t = util.gen_inputs(case)
+    idx = np.arange(B) % s.B
+    from nv_wavenet_amd import WavenetEngine
+    e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, B, s.N, impl=case.impl, tanhEmbed=True, precision=32)
+    e.setEmbeddings(t.embP, t.embC)
+    for l in range(s.L):
+        e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
+    e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
+    Lh = np.ascontiguousarray(t.Lh[:, :, idx, :])            # [N][L][B][2R]
+    sel = np.ascontiguousarray(t.sel[:, idx])                # [N][B]
+    e.setInputs(Lh, sel)
+    y = np.full((B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, B, y, 1, False)
+    e.synchronize()
+    assert np.array_equal(y, g["yOut"][0][idx]), "utterance %d differs" % int(np.argwhere((y != g["yOut"][0][idx]).any(axis=1))[0, 0])
+    e.close()
+
+
+@pytest.mark.parametrize("B,small_mode", [(4112, "wg"), (8208, "stream")])
+def test_full_chip_batches_by_replication_fp16(B, small_mode):
+    """The same property for the fp16 production path (dump-free kernels, engine's own choice of
+    organisation at full-chip batch sizes): the big batch must repeat, bit for bit, what the same
+    organisation generates for the 19 utterances alone (one tile per workgroup for 'wg': one and two
+    tiles per workgroup perform the same arithmetic per utterance)."""
+    case = cases.BY_NAME["R64S128A256_L7_B19_oddL"]
+    s = case.shape
+    t = util.gen_inputs(case, half=True)
+    e0 = util.make_engine(case, t, precision=16, mode=small_mode)
+    y0 = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e0.run(s.N, s.B, y0, 1, False)
+    e0.synchronize()
+    e0.close()
+    idx = np.arange(B) % s.B
+    from nv_wavenet_amd import WavenetEngine
+    e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, B, s.N, impl=case.impl, tanhEmbed=True, precision=16)
+    e.setEmbeddings(t.embP, t.embC)
+    for l in range(s.L):
+        e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
+    e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
+    e.setInputs(np.ascontiguousarray(t.Lh[:, :, idx, :]), np.ascontiguousarray(t.sel[:, idx]))
+    y = np.full((B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, B, y, 1, False)
+    e.synchronize()
+    assert np.array_equal(y, y0[idx])
+    e.close()
