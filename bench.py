@@ -322,14 +322,17 @@ def main():
         passes = (tiles + 3) // 4 if stream_mode else (tiles + bt - 1) // bt
         kname = "wn::wavenet_stream<fp16,64,256,256>" if stream_mode else "wn::wavenet_wg<fp16,64,256,256,BT=%d>" % bt
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tf):
+        # HBM bytes per launch from the PMC passes of the latest profiled round (profiles/traffic_rNN.json,
+        # written by scripts/make_profiles.sh); only valid for the launch shape it was measured on
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
             try:
                 tj = json.load(open(tf))
                 if tj.get("batch") == B and tj.get("samples") == N:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    break
             except Exception:
-                traffic = None
+                pass
         roofline = dict(bound="mfma", achieved=flops / (kern_ms * 1e-3) / 1e12, peak=MFMA_F16_PEAK_TFLOPS,
                         unit="TFLOP/s", traffic=traffic, kernel=kname,
                         kernel_ms=kern_ms,
