@@ -121,10 +121,10 @@ protected:
         gpuErrChk(hipStreamSynchronize(0));
     }
     // same for the shared stream of the throughput kernel (fragment offset inside the one stream)
-    void packWeightStream(size_t fragOff, const float* src, int M, int K, int rowperm) {
+    void packWeightStream(size_t fragOff, const float* src, int M, int K, int rowperm, int gate = 0) {
         const float* d = onDevice(src, (size_t)M * K);
         hipLaunchKernelGGL((wn::pack_weight_stream_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0,
-                           m_wblob + fragOff * SC::FRAG_ELEMS, d, M, K, rowperm);
+                           m_wblob + fragOff * SC::FRAG_ELEMS, d, M, K, rowperm, gate);
         gpuErrChk(hipGetLastError());
         gpuErrChk(hipStreamSynchronize(0));
     }
@@ -318,8 +318,8 @@ public:
         const size_t lf = (size_t)layer * C::FLW;
         if (m_streamMode) {
             const size_t sf = (size_t)layer * SC::FLP;
-            packWeightStream(sf + SC::O_PREV, Wprev, 2 * R, R, 0);
-            packWeightStream(sf + SC::O_CUR, Wcur, 2 * R, R, 0);
+            packWeightStream(sf + SC::O_PREV, Wprev, 2 * R, R, 0, 1);
+            packWeightStream(sf + SC::O_CUR, Wcur, 2 * R, R, 0, 1);
             packWeightStream(sf + SC::O_RES, Wres, R, R, 0);
             // the skip GEMM of layer l is consumed one body later (the head body after the last layer)
             const size_t skipAt = (layer + 1 < m_numLayers) ? sf + SC::FLP + SC::O_SKIP
@@ -333,6 +333,11 @@ public:
         }
         float* b = m_bias + (size_t)layer * C::BIAS_L;
         gpuErrChk(hipMemcpy(b, Bh, 2 * R * sizeof(float), hipMemcpyDefault));
+        if constexpr (F16) {   // the fp16 gate works on pre-scaled pre-activations (wn::gate1)
+            hipLaunchKernelGGL((wn::scale_gate_bias_kernel<F16>), dim3(1), dim3(256), 0, 0, b, R);
+            gpuErrChk(hipGetLastError());
+            gpuErrChk(hipStreamSynchronize(0));
+        }
         gpuErrChk(hipMemcpy(b + 2 * R, Bres, R * sizeof(float), hipMemcpyDefault));
         gpuErrChk(hipMemcpy(b + 3 * R, Bskip, S * sizeof(float), hipMemcpyDefault));
     }

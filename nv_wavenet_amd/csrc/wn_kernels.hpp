@@ -288,50 +288,35 @@ template <bool F16> WN_DEV float tanh_t(float x) { return F16 ? tanh_fast(x) : t
 template <bool F16> WN_DEV float tanh_t(float x) { return x; }
 #endif
 
-// ---- the gate  h = tanh(a) * sigmoid(b)  on 4 values -------------------------------------------
+// ---- the gate  h = tanh(a) * sigmoid(b) ---------------------------------------------------------
 // fp32 engine: the accurate scalar forms above (parity bars are relative, nv_wavenet_test.cu:273-298).
-// fp16 engine: exp/rcp forms as well.  (An alternative kept under WN_PADE_GATE evaluates the gate as
-// ONE rational function with a single reciprocal instead of 2 exp + 2 rcp per value; measured on
-// MI355X it is SLOWER -- 1770 vs 1470 clk per layer in wavenet_stream -- the transcendental pipe is
-// not the bottleneck, the extra packed FMAs are:
-//   tanh(x) ~ N(x)/D(x), the (7,6) Pade approximant, x clamped to +-4.97 (|error| < 1e-4 everywhere);
-//   sigmoid(b) = 0.5 + 0.5 tanh(b/2)  =>  h = Na (Db + Nb) / (2 Da Db).   Max |error| of h: 1.2e-4.
-// Everything but the reciprocal is packed-fp32 FMA work.
-template <bool F16> WN_DEV floatx4 gate4(floatx4 a, floatx4 b);
-template <> WN_DEV floatx4 gate4<false>(floatx4 a, floatx4 b) {
-    floatx4 h;
-#pragma unroll
-    for (int r = 0; r < 4; r++) h[r] = tanh_t<false>(a[r]) * sigmoid_f(b[r]);
-    return h;
+// fp16 engine: the gate pre-activations arrive PRE-SCALED -- tanh rows by 2 log2(e), sigmoid rows by
+// -log2(e), folded into Wprev, Wcur, Bh and the conditioning when they are packed (gate_prescale below)
+// -- so the gate is exp2 / rcp with no multiplications in front:
+//     tanh(a) = 1 - 2 / (2^a' + 1),   sigmoid(b) = 1 / (1 + 2^b').
+// (Tried and slower on MI355X: the gate as one rational function with a single reciprocal, (7,6) Pade
+// approximant of tanh: 1770 vs 1470 clk per layer in wavenet_stream -- the extra FMAs cost more than
+// the transcendentals they save; a lone wave issues a v_exp_f32 every 8.9 clk, a v_fma_f32 every 5.8.)
+template <bool F16> __host__ __device__ constexpr float gate_prescale(bool sigmoidRow) {
+    return !F16 ? 1.0f : sigmoidRow ? -1.44269504088896340736f : 2.88539008177792681472f;
 }
+template <bool F16> WN_DEV float gate1(float a, float b);
 #ifdef WN_ABL_NOACT
-template <> WN_DEV floatx4 gate4<true>(floatx4 a, floatx4 b) { return a * b; }
-#elif defined(WN_PADE_GATE)
-template <> WN_DEV floatx4 gate4<true>(floatx4 a, floatx4 b) {
-    const float CL = 4.97f;
-    a = __builtin_elementwise_min(__builtin_elementwise_max(a, floatx4{-CL, -CL, -CL, -CL}), floatx4{CL, CL, CL, CL});
-    b = b * 0.5f;
-    b = __builtin_elementwise_min(__builtin_elementwise_max(b, floatx4{-CL, -CL, -CL, -CL}), floatx4{CL, CL, CL, CL});
-    const floatx4 a2 = a * a, b2 = b * b;
-    const floatx4 na = a * (135135.f + a2 * (17325.f + a2 * (378.f + a2)));
-    const floatx4 da = 135135.f + a2 * (62370.f + a2 * (3150.f + a2 * 28.f));
-    const floatx4 nb = b * (135135.f + b2 * (17325.f + b2 * (378.f + b2)));
-    const floatx4 db = 135135.f + b2 * (62370.f + b2 * (3150.f + b2 * 28.f));
-    const floatx4 num = na * (db + nb);
-    const floatx4 den = (da * db) * 2.0f;
-    floatx4 h;
-#pragma unroll
-    for (int r = 0; r < 4; r++) h[r] = num[r] * fast_rcp(den[r]);
-    return h;
-}
+template <> WN_DEV float gate1<false>(float a, float b) { return a * b; }
+template <> WN_DEV float gate1<true>(float a, float b) { return a * b; }
 #else
-template <> WN_DEV floatx4 gate4<true>(floatx4 a, floatx4 b) {
-    floatx4 h;
-#pragma unroll
-    for (int r = 0; r < 4; r++) h[r] = tanh_t<true>(a[r]) * sigmoid_f(b[r]);
-    return h;
+template <> WN_DEV float gate1<false>(float a, float b) { return tanh_acc(a) * sigmoid_f(b); }
+template <> WN_DEV float gate1<true>(float a, float b) {
+    const float t = 1.0f - 2.0f * fast_rcp(__builtin_amdgcn_exp2f(a) + 1.0f);
+    return t * fast_rcp(1.0f + __builtin_amdgcn_exp2f(b));
 }
 #endif
+template <bool F16> WN_DEV floatx4 gate4(floatx4 a, floatx4 b) {
+    floatx4 h;
+#pragma unroll
+    for (int r = 0; r < 4; r++) h[r] = gate1<F16>(a[r], b[r]);
+    return h;
+}
 
 WN_DEV floatx4 mma(half8 a, half8 b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -1130,7 +1115,9 @@ __global__ void pack_weight_kernel(typename Prec<F16>::elem* __restrict__ dst, c
         const int i = lane & 15, g = lane >> 4;
         const int m = tile * 16 + i;
         const int k = (kf * TPF + (e >> 2)) * 16 + g * 4 + (e & 3);
-        dst[(size_t)w * waveStride + (idx % perWave)] = (typename Prec<F16>::elem)src[(size_t)m + (size_t)k * M];
+        float v = src[(size_t)m + (size_t)k * M];
+        if (gateRT > 0) v *= gate_prescale<F16>(m >= M / 2);    // gated 2R x R matrix: see gate1()
+        dst[(size_t)w * waveStride + (idx % perWave)] = (typename Prec<F16>::elem)v;
     }
 }
 
@@ -1165,9 +1152,15 @@ __global__ void pack_cond_kernel(typename Prec<F16>::elem* __restrict__ dst, con
         const int tile = w + NW * (it >> 1) + (it & 1) * RT;
         const int ch = tile * 16 + g * 4 + (e & 3);
         float v = 0.f;
-        if (b < maxBatch) v = src[(row * maxBatch + b) * 2 * R + ch];
+        if (b < maxBatch) v = src[(row * maxBatch + b) * 2 * R + ch] * gate_prescale<F16>(ch >= R);
         dst[idx] = (typename Prec<F16>::elem)v;
     }
+}
+
+// Bh (2R gate biases of one layer, fp32, in place): the pre-scaling of gate1()
+template <bool F16> __global__ void scale_gate_bias_kernel(float* bh, int R) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * R; i += gridDim.x * blockDim.x)
+        bh[i] *= gate_prescale<F16>(i >= R);
 }
 
 static __global__ void silence_kernel(int* yInPrev, int* yInCur, int n) {

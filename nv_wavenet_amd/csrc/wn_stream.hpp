@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
                             const int tt = v >> 2, r = v & 3;
                             const float zl = acc[tt][r] + (float)cd[tt / P::TPF][(tt % P::TPF) * 4 + r];
                             const float zh = acc[tt + RT][r] + (float)cd[(tt + RT) / P::TPF][((tt + RT) % P::TPF) * 4 + r];
-                            h[tt][r] = tanh_t<F16>(zl) * sigmoid_f(zh);
+                            h[tt][r] = gate1<F16>(zl, zh);
                             vdone = v + 1;
                         }
                     }
@@ -518,10 +518,11 @@ __global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const i
 }
 
 // ---- pack kernels for the shared stream -----------------------------------------------------------
-// fp32 col-major M x K -> fragments (mt-major, kf-minor); rowperm: lane-contiguous rows (logits)
+// fp32 col-major M x K -> fragments (mt-major, kf-minor); rowperm: lane-contiguous rows (logits);
+// gate: a gated 2R x R matrix (rows pre-scaled for gate1())
 template <bool F16>
 __global__ void pack_weight_stream_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src,
-                                          int M, int K, int rowperm) {
+                                          int M, int K, int rowperm, int gate) {
     constexpr int EPL = Prec<F16>::EPL, TPF = Prec<F16>::TPF;
     const int KF = K / (16 * TPF);
     const size_t n = (size_t)M * K;
@@ -535,7 +536,9 @@ __global__ void pack_weight_stream_kernel(typename Prec<F16>::elem* __restrict__
         const int i = lane & 15, g = lane >> 4;
         const int m = rowperm ? ((i >> 2) * (M / 4) + mt * 4 + (i & 3)) : (mt * 16 + i);
         const int k = (kf * TPF + (e >> 2)) * 16 + g * 4 + (e & 3);
-        dst[idx] = (typename Prec<F16>::elem)src[(size_t)m + (size_t)k * M];
+        float v = src[(size_t)m + (size_t)k * M];
+        if (gate) v *= gate_prescale<F16>(m >= M / 2);          // gated 2R x R matrix: see gate1()
+        dst[idx] = (typename Prec<F16>::elem)v;
     }
 }
 
@@ -558,7 +561,7 @@ __global__ void pack_cond_stream_kernel(typename Prec<F16>::elem* __restrict__ d
         const int b = tl * 16 + j;
         const int ch = (c * TPF + (e >> 2)) * 16 + g * 4 + (e & 3);
         float v = 0.f;
-        if (b < maxBatch) v = src[(row * maxBatch + b) * R2 + ch];
+        if (b < maxBatch) v = src[(row * maxBatch + b) * R2 + ch] * gate_prescale<F16>(ch >= R2 / 2);
         dst[idx] = (typename Prec<F16>::elem)v;
     }
 }
