@@ -96,7 +96,8 @@ template <int KT> WN_DEV void to_bfrags(const floatx4 (&t)[KT], floatx4 (&b)[KT]
 // DUMP: see wn::wavenet_wg -- production launches use the variant without any activation-dump code
 // (57.5 instead of 62.3 us per sample at batch 16384).
 template <bool F16, int R, int S, int A, bool DUMP = true>
-__global__ __launch_bounds__(512, 2) void wavenet_stream(const Params p, const int NS) {
+// one workgroup per CU (its LDS ring fills the CU): the whole 256-register budget per wave
+__global__ __launch_bounds__(512, 1) void wavenet_stream(const Params p, const int NS) {
     using C = SCfg<F16, R, S, A>;
     using P = Prec<F16>;
     using frag = typename P::frag;
