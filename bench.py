@@ -258,6 +258,7 @@ def main():
                "kernel": "wn::wavenet_stream", "real_time": bool(khz_t >= REALTIME_KHZ)}
 
     e = build_engine(w, B, N)
+    kinfo = e.kernelInfo(B, False)
     Lh, sel = device_inputs(B, N, 100 + rank)
     e.setInputs(Lh, sel)
     del Lh, sel
@@ -320,7 +321,8 @@ def main():
         bt = 2 if tiles > ncu else 1                            # tiles per workgroup of the latency kernel
         # workgroups (weight-stream passes) per sample
         passes = (tiles + 3) // 4 if stream_mode else (tiles + bt - 1) // bt
-        kname = "wn::wavenet_stream<fp16,64,256,256>" if stream_mode else "wn::wavenet_wg<fp16,64,256,256,BT=%d>" % bt
+        kname = kinfo.split(" ")[0]                             # what the engine reports it launches
+        assert ("stream" in kname) == stream_mode and (stream_mode or "BT=%d" % bt in kname), kinfo
         traffic = None
         # HBM bytes per launch from the PMC passes of the latest profiled round (profiles/traffic_rNN.json,
         # written by scripts/make_profiles.sh); only valid for the launch shape it was measured on
@@ -334,7 +336,7 @@ def main():
             except Exception:
                 pass
         roofline = dict(bound="mfma", achieved=flops / (kern_ms * 1e-3) / 1e12, peak=MFMA_F16_PEAK_TFLOPS,
-                        unit="TFLOP/s", traffic=traffic, kernel=kname,
+                        unit="TFLOP/s", traffic=traffic, kernel=kname, launch=kinfo,
                         kernel_ms=kern_ms,
                         hbm=dict(achieved=units * HBM_BYTES / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"),
                         l2_weight_stream=dict(achieved=passes * N * WEIGHT_BYTES / (kern_ms * 1e-3) / 1e9,

@@ -62,6 +62,9 @@ void nvw_set_inputs(nvw_engine* e, float* Lh, float* output_selectors);
 void nvw_set_conditioning(nvw_engine* e, float* Lh);
 void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed);
 void nvw_set_audio_out(nvw_engine* e, short* pcm_out);
+/* Introspection: the device code nvw_run(e, n, batch_size, ..., dump_activations, ...) launches, e.g.
+ * "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=1,DUMP=0> tiles/wg=2 wgs=256 lds=149120" */
+void nvw_kernel_info(nvw_engine* e, int batch_size, int dump_activations, char* buf, int buf_size);
 
 int nvw_run(nvw_engine* e, int num_samples, int batch_size, int* yOut, int batch_size_per_block,
             int dump_activations, void* stream);

@@ -34,6 +34,7 @@ SIGNATURES = {
     "nvw_set_conditioning": (None, [C.c_void_p, _fp]),
     "nvw_set_selector_seed": (None, [C.c_void_p, C.c_ulonglong]),
     "nvw_set_audio_out": (None, [C.c_void_p, C.c_void_p]),
+    "nvw_kernel_info": (None, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "nvw_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_void_p]),
     "nvw_run_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_void_p]),
     "nvw_run_chunks": (C.c_int, [C.c_void_p, C.c_int, CONSUME_FN, C.c_void_p, C.c_int, C.c_int, _fp, C.c_int,

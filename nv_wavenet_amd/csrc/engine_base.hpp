@@ -14,6 +14,7 @@ struct nvw_engine {
     virtual void setConditioning(float*) = 0;
     virtual void setSelectorSeed(unsigned long long) = 0;
     virtual void setAudioOut(short*) = 0;
+    virtual void kernelInfo(int, bool, char*, int) = 0;
     virtual bool run(int, int, int*, int, bool, hipStream_t) = 0;
     virtual bool run_partial(int, int, int, int*, int, bool, hipStream_t) = 0;
     virtual bool run_chunks(int, nvw_consume_fn, void*, int, int, int*, int, bool, hipStream_t) = 0;
@@ -38,6 +39,7 @@ struct EngineImpl : nvw_engine {
     void setConditioning(float* Lh) override { eng.setConditioning(Lh); }
     void setSelectorSeed(unsigned long long seed) override { eng.setSelectorSeed(seed); }
     void setAudioOut(short* pcm) override { eng.setAudioOut(pcm); }
+    void kernelInfo(int b, bool dump, char* buf, int n) override { eng.kernelInfo(b, dump, buf, n); }
     bool run(int n, int b, int* y, int bspb, bool dump, hipStream_t s) override {
         return eng.run(n, b, y, bspb, dump, s);
     }

@@ -424,6 +424,24 @@ public:
                                    stream));
     }
 
+    // Which device code run(num_samples, batch_size, ..., dumpActivations) launches: kernel name with its
+    // template arguments, tiles per workgroup, workgroups, dynamic LDS bytes (for benchmarks / logs).
+    void kernelInfo(int batch_size, bool dumpActivations, char* buf, int n) const {
+        const int tiles = (batch_size + 15) / 16;
+        const bool dump = F16 ? dumpActivations : true;
+        if (m_streamMode) {
+            snprintf(buf, n, "wn::wavenet_stream<%s,%d,%d,%d,DUMP=%d> tiles/wg=4 wgs=%d lds=%zu", F16 ? "fp16" : "fp32", R,
+                     S, A, dump ? 1 : 0, (tiles + 3) / 4, SC::ldsBytes(m_numLayers, m_streamNS));
+            return;
+        }
+        const bool two = (m_forceBt ? m_forceBt == 2 : tiles > m_numCUs) && ldsFits<2>();
+        const int bt = two ? 2 : 1;
+        const int nEmb = two ? embTables<2>() : embTables<1>();
+        snprintf(buf, n, "wn::wavenet_wg<%s,%d,%d,%d,BT=%d,EMBLDS=%d,DUMP=%d> tiles/wg=%d wgs=%d lds=%zu",
+                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, bt, (tiles + bt - 1) / bt,
+                 two ? ldsNeed<2>(m_numLayers, nEmb) : ldsNeed<1>(m_numLayers, nEmb));
+    }
+
     // ---- debug getters: last generated sample's activations, reference layouts --------------
     void getXtOut(int layer, float* hXt) {
         gpuErrChk(hipMemcpy(hXt, m_XtOut + (size_t)layer * m_maxBatch * R, (size_t)m_maxBatch * R * sizeof(float),

@@ -67,6 +67,9 @@ void nvw_set_inputs(nvw_engine* e, float* Lh, float* sel) { e->setInputs(Lh, sel
 void nvw_set_conditioning(nvw_engine* e, float* Lh) { e->setConditioning(Lh); }
 void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed) { e->setSelectorSeed(seed); }
 void nvw_set_audio_out(nvw_engine* e, short* pcmOut) { e->setAudioOut(pcmOut); }
+void nvw_kernel_info(nvw_engine* e, int batch_size, int dump_activations, char* buf, int buf_size) {
+    e->kernelInfo(batch_size, dump_activations != 0, buf, buf_size);
+}
 
 int nvw_run(nvw_engine* e, int num_samples, int batch_size, int* yOut, int bspb, int dump, void* stream) {
     return e->run(num_samples, batch_size, yOut, bspb, dump != 0, (hipStream_t)stream) ? 1 : 0;

@@ -94,6 +94,14 @@ class WavenetEngine:
         assert (Lh.numel() if hasattr(Lh, "numel") else Lh.size) == n, "Lh has the wrong size"
         lib.nvw_set_conditioning(self._h, addr(Lh))
 
+    def kernelInfo(self, batch_size=None, dumpActivations=False):
+        """The device code run(n, batch_size, ..., dumpActivations) launches (kernel + template arguments)."""
+        import ctypes
+        buf = ctypes.create_string_buffer(256)
+        lib.nvw_kernel_info(self._h, self.maxBatch if batch_size is None else batch_size, 1 if dumpActivations else 0,
+                            buf, 256)
+        return buf.value.decode()
+
     def setSelectorSeed(self, seed):
         """Selectors are drawn in-kernel (Philox4x32-10, counter {sample, utterance, 0, 0}, key=seed)."""
         lib.nvw_set_selector_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF)

@@ -381,6 +381,15 @@ def test_full_chip_batches_by_replication_fp16(B, small_mode):
         e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
     e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
     e.setInputs(np.ascontiguousarray(t.Lh[:, :, idx, :]), np.ascontiguousarray(t.sel[:, idx]))
+    # the engine reports what it launches: dump-free kernels; two tiles per workgroup beyond one tile
+    # per CU, the loader/consumer kernel beyond two
+    import torch
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = (B + 15) // 16
+    info = e.kernelInfo(B, False)
+    assert "DUMP=0" in info and "fp16" in info, info
+    want = "wavenet_stream" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
+    assert want in info, (info, ncu)
     y = np.full((B, s.N), -1, dtype=np.int32)
     assert e.run(s.N, B, y, 1, False)
     e.synchronize()
