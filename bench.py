@@ -271,15 +271,16 @@ def main():
 
     def step(i, events=None):
         y = ybuf[i % 2]
+        # the gather of step i overlaps the kernel of step i+1 (RCCL runs on its own stream); the gather
+        # of step i-2 read the buffer this step overwrites, so it is completed first
+        while len(pending) > 1:
+            pending.pop(0)()
         if events is not None:
             events[0].record(stream)
         assert e.run(N, B, y, 1, False, sptr)
         if events is not None:
             events[1].record(stream)
         if world > 1:
-            # the gather of step i overlaps the kernel of step i+1 (RCCL runs on its own stream)
-            while len(pending) > 1:
-                pending.pop(0)()
             _, fin = gather_samples(y, B * world, async_op=True)
             pending.append(fin)
 
