@@ -395,3 +395,52 @@ def test_full_chip_batches_by_replication_fp16(B, small_mode):
     e.synchronize()
     assert np.array_equal(y, y0[idx])
     e.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("precision", [32, 16])
+def test_no_tanh_on_the_embedding(mode, precision):
+    """tanhEmbed = false is what the PyTorch path uses (WaveNet.export_weights sets use_embed_tanh False,
+    pytorch/wavenet.py:186) although the reference's CPU class always applies the tanh
+    (nv_wavenet_reference.cpp:52); the oracle restatement carries the flag. fp32: exact indices and the
+    reference harness's activation bars; fp16: the stated fp16 bar."""
+    from nv_wavenet_amd import WavenetEngine
+    case = cases.BY_NAME["C3_R64S256A256_L20_B21"]
+    s = case.shape
+    t = util.gen_inputs(case, half=(precision == 16))
+    t.embP *= 100.0    # make the tanh matter: |x0| up to ~0.8
+    t.embC *= 100.0
+    if precision == 16:
+        t.round_to_half()
+    o = util.make_oracle(case, t)
+    o.set_tanh_embed(False)
+    y_ref = o.run(s.N)
+    o2 = util.make_oracle(case, t)          # sanity: the flag changes the residual stream well beyond the bars
+    o2.run(s.N)
+    x_on, x_off = o2.getters()["Xout"], o.getters()["Xout"]
+    assert np.abs(x_on - x_off).max() > 0.05 * np.abs(x_off).max()
+    o2.close()
+    import os
+    old = os.environ.get("NVW_MODE")
+    os.environ["NVW_MODE"] = mode
+    try:
+        e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, s.B, s.N, impl=case.impl, tanhEmbed=False, precision=precision)
+    finally:
+        if old is None:
+            os.environ.pop("NVW_MODE", None)
+        else:
+            os.environ["NVW_MODE"] = old
+    e.setEmbeddings(t.embP, t.embC)
+    for l in range(s.L):
+        e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
+    e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
+    e.setInputs(t.Lh, t.sel)
+    y = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, s.B, y, 1, True)
+    e.synchronize()
+    if precision == 32:
+        util.compare_activations(o.getters(), util.engine_getters(e, s.L))
+        assert np.array_equal(y, y_ref)
+    else:
+        assert np.all(y == y_ref, axis=1).mean() >= 0.9
+    e.close(), o.close()
