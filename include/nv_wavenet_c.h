@@ -42,6 +42,16 @@ int nvw_list_supported(int* out, int max);
 
 nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int max_dilation,
                        int batch_size, int num_samples, int implementation, int tanh_embed);
+/* The same with an explicit kernel organisation (the last, optional argument of this repo's nvWavenetInfer
+ * constructor; 0 = from `implementation` and the batch size like nvw_create):
+ *   1 wavenet_wg (1 or 2 tiles of 16 utterances per workgroup by batch size)   2 / 3 wavenet_wg with exactly 1 / 2
+ *   4 wavenet_stream (loader / consumer waves)   5 wavenet_chain (multi-CU, resident weights, fewest CUs)
+ *   6 wavenet_chain with one layer per CU.
+ * Returns NULL when the shape does not fit a CU in that organisation (the reference's variants print
+ * and return false for shapes they do not support, nv_wavenet_singleblock.cuh:273-286). */
+nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, int max_dilation,
+                          int batch_size, int num_samples, int implementation, int tanh_embed,
+                          int organisation);
 void nvw_destroy(nvw_engine* e);
 
 void nvw_set_embeddings(nvw_engine* e, float* embed_prev, float* embed_cur);
@@ -60,6 +70,17 @@ void nvw_set_inputs(nvw_engine* e, float* Lh, float* output_selectors);
  *                          the run calls wherever yOut is: int16(32768 * mu_law_decode(y, A)); NULL
  *                          switches it off */
 void nvw_set_conditioning(nvw_engine* e, float* Lh);
+/* Utterances shorter than the engine's capacity: num_samples <= the num_samples of nvw_create rows of
+ * Lh / output_selectors (both layouts are sample-major, so a prefix is a complete input) */
+void nvw_set_inputs_n(nvw_engine* e, float* Lh, float* output_selectors, int num_samples);
+void nvw_set_conditioning_n(nvw_engine* e, float* Lh, int num_samples);
+/* Conditioning streamed chunk by chunk: packs samples [first_sample, first_sample + count) (Lh points at
+ * sample first_sample, device memory) asynchronously on `stream`, e.g. behind nvw_run_partial of the
+ * previous chunk on another stream.  Does not touch the sample history. */
+void nvw_pack_conditioning(nvw_engine* e, float* Lh, int first_sample, int count, void* stream);
+/* 0 when every multi-CU (wavenet_chain) launch so far ran to completion, else the code of the first
+ * hand-off that timed out; synchronises the device */
+unsigned nvw_chain_status(nvw_engine* e);
 void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed);
 void nvw_set_audio_out(nvw_engine* e, short* pcm_out);
 /* Introspection: the device code nvw_run(e, n, batch_size, ..., dump_activations, ...) launches, e.g.

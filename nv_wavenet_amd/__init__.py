@@ -11,4 +11,4 @@ Python host side mirroring the reference's ``pytorch/`` wrapper:
 There is no CPU fallback: importing ``_lib`` without the built library raises.
 """
 from . import _lib  # noqa: F401  (fails loudly when the HIP library is missing)
-from .engine import WavenetEngine, Impl, supported_configs  # noqa: F401
+from .engine import WavenetEngine, Impl, Org, supported_configs  # noqa: F401

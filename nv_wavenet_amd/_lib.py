@@ -26,12 +26,17 @@ SIGNATURES = {
     "nvw_supported": (C.c_int, [C.c_int] * 4),
     "nvw_list_supported": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "nvw_create": (C.c_void_p, [C.c_int] * 10),
+    "nvw_create_ex": (C.c_void_p, [C.c_int] * 11),
     "nvw_destroy": (None, [C.c_void_p]),
     "nvw_set_embeddings": (None, [C.c_void_p, _fp, _fp]),
     "nvw_set_layer_weights": (None, [C.c_void_p, C.c_int] + [_fp] * 7),
     "nvw_set_out_weights": (None, [C.c_void_p] + [_fp] * 4),
     "nvw_set_inputs": (None, [C.c_void_p, _fp, _fp]),
     "nvw_set_conditioning": (None, [C.c_void_p, _fp]),
+    "nvw_set_inputs_n": (None, [C.c_void_p, _fp, _fp, C.c_int]),
+    "nvw_set_conditioning_n": (None, [C.c_void_p, _fp, C.c_int]),
+    "nvw_pack_conditioning": (None, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_void_p]),
+    "nvw_chain_status": (C.c_uint, [C.c_void_p]),
     "nvw_set_selector_seed": (None, [C.c_void_p, C.c_ulonglong]),
     "nvw_set_audio_out": (None, [C.c_void_p, C.c_void_p]),
     "nvw_kernel_info": (None, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]),

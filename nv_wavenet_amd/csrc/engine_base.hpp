@@ -10,8 +10,12 @@ struct nvw_engine {
     virtual void setEmbeddings(float*, float*) = 0;
     virtual void setLayerWeights(int, float*, float*, float*, float*, float*, float*, float*) = 0;
     virtual void setOutWeights(float*, float*, float*, float*) = 0;
-    virtual void setInputs(float*, float*) = 0;
-    virtual void setConditioning(float*) = 0;
+    virtual void setInputs(float*, float*, int) = 0;
+    virtual void setConditioning(float*, int) = 0;
+    virtual void packConditioning(float*, int, int, hipStream_t) = 0;
+    virtual bool supported() = 0;
+    virtual unsigned chainStatus() = 0;
+    virtual int maxSamples() = 0;
     virtual void setSelectorSeed(unsigned long long) = 0;
     virtual void setAudioOut(short*) = 0;
     virtual void kernelInfo(int, bool, char*, int) = 0;
@@ -29,14 +33,19 @@ struct nvw_engine {
 template <typename Tw, typename Td, int R, int S, int A>
 struct EngineImpl : nvw_engine {
     nvWavenetInfer<Tw, Td, R, S, A> eng;
-    EngineImpl(int L, int maxD, int B, int N, int impl, bool tanhEmbed) : eng(L, maxD, B, N, impl, tanhEmbed) {}
+    int cap;
+    EngineImpl(int L, int maxD, int B, int N, int impl, bool tanhEmbed, int org) : eng(L, maxD, B, N, impl, tanhEmbed, org), cap(N) {}
     void setEmbeddings(float* p, float* c) override { eng.setEmbeddings(p, c); }
     void setLayerWeights(int l, float* a, float* b, float* c, float* d, float* e, float* f, float* g) override {
         eng.setLayerWeights(l, a, b, c, d, e, f, g);
     }
     void setOutWeights(float* a, float* b, float* c, float* d) override { eng.setOutWeights(a, b, c, d); }
-    void setInputs(float* Lh, float* sel) override { eng.setInputs(Lh, sel); }
-    void setConditioning(float* Lh) override { eng.setConditioning(Lh); }
+    void setInputs(float* Lh, float* sel, int n) override { eng.setInputs(Lh, sel, n); }
+    void setConditioning(float* Lh, int n) override { eng.setConditioning(Lh, n); }
+    void packConditioning(float* Lh, int first, int count, hipStream_t s) override { eng.packConditioning(Lh, first, count, s); }
+    bool supported() override { return eng.supported(); }
+    unsigned chainStatus() override { return eng.chainStatus(); }
+    int maxSamples() override { return cap; }
     void setSelectorSeed(unsigned long long seed) override { eng.setSelectorSeed(seed); }
     void setAudioOut(short* pcm) override { eng.setAudioOut(pcm); }
     void kernelInfo(int b, bool dump, char* buf, int n) override { eng.kernelInfo(b, dump, buf, n); }
@@ -59,7 +68,7 @@ struct EngineImpl : nvw_engine {
     void getYOut(int* y, int off, int size, hipStream_t s) override { eng.getYOut(y, off, size, s); }
 };
 
-typedef nvw_engine* (*nvw_factory_fn)(int L, int maxD, int B, int N, int impl, int tanhEmbed);
+typedef nvw_engine* (*nvw_factory_fn)(int L, int maxD, int B, int N, int impl, int tanhEmbed, int organisation);
 
 #define WN_CAT2(a, b) a##b
 #define WN_CAT(a, b) WN_CAT2(a, b)

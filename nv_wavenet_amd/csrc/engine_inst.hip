@@ -10,6 +10,6 @@ typedef float Tw;
 typedef float Td;
 #endif
 
-nvw_engine* WN_FACTORY_NAME(WN_R, WN_S, WN_A, WN_P)(int L, int maxD, int B, int N, int impl, int tanhEmbed) {
-    return new EngineImpl<Tw, Td, WN_R, WN_S, WN_A>(L, maxD, B, N, impl, tanhEmbed != 0);
+nvw_engine* WN_FACTORY_NAME(WN_R, WN_S, WN_A, WN_P)(int L, int maxD, int B, int N, int impl, int tanhEmbed, int organisation) {
+    return new EngineImpl<Tw, Td, WN_R, WN_S, WN_A>(L, maxD, B, N, impl, tanhEmbed != 0, organisation);
 }

@@ -5,14 +5,23 @@
 // setOutWeights / setInputs, run / run_partial / run_chunks and debug getters, with the same
 // argument meaning, layouts (col-major fp32 weights in, host OR device pointers, data copied),
 // defaults and error convention (HIP errors print "GPUassert: ..." and exit, precondition
-// violations assert, nv_wavenet_util.cuh:34-40).  Streams are hipStream_t.
+// violations assert, unsupported shapes make run() return false, nv_wavenet_util.cuh:34-40,
+// nv_wavenet_singleblock.cuh:273-286).  Streams are hipStream_t.
 //
-// What is different underneath (see wn_kernels.hpp): all Implementation values run the
-// MFMA engine (one 4-wave workgroup per tile of 16 utterances, M split over the waves);
-// batch_size_per_block is validated like the reference (nv_wavenet.cuh:559-561) but the batch
-// tile is fixed by the MFMA shape (16 utterances, 1 or 2 tiles per workgroup chosen from the
-// batch size), so it is a no-op hint.  Device buffers are laid out for that engine, not for the
-// reference's kernels; the getters return the reference's layouts.
+// What is different underneath.  `Implementation` selects between device-code ORGANISATIONS of the
+// same MFMA engine (all parity-tested against each other and the oracle):
+//   SINGLE_BLOCK            one workgroup runs the whole network for its utterance tile(s), weights
+//                           streamed from L2 every sample: wn::wavenet_wg (1 or 2 tiles of 16 utterances
+//                           per workgroup) or, beyond two tiles per CU, wn::wavenet_stream
+//   DUAL_BLOCK, PERSISTENT  wn::wavenet_chain: the layer stack split over a chain of CUs, each holding
+//                           its layers' weights resident in registers + LDS, plus a head CU; hand-offs
+//                           through L2-visible tagged granules (wn_chain.hpp); fewest CUs that hold the model
+//   MANYBLOCK_NONPERSISTENT the same chain with one layer per CU
+//   AUTO                    chosen from (R, S, A, L, batch, CUs): see pickOrganisation()
+// An explicit Organisation (last constructor argument, beyond the reference's signature) overrides.
+// batch_size_per_block is validated like the reference (nv_wavenet.cuh:559-561) but the batch tile is
+// fixed by the MFMA shape (16 utterances), so it is a no-op hint.  Device buffers are laid out for this
+// engine, not for the reference's kernels; the getters return the reference's layouts.
 #pragma once
 
 #include <assert.h>
@@ -26,6 +35,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "wn_chain.hpp"
 #include "wn_kernels.hpp"
 #include "wn_stream.hpp"
 
@@ -38,6 +48,17 @@ inline void wnGpuAssert(hipError_t code, const char* file, int line, bool abort 
     }
 }
 #endif
+
+// kernel organisations (beyond the reference: its Implementation enum maps onto these, see above)
+enum nvwOrganisation {
+    NVW_ORG_AUTO = 0,     // from Implementation and the batch size
+    NVW_ORG_WG = 1,       // wn::wavenet_wg, 1 or 2 tiles per workgroup by batch size
+    NVW_ORG_WG1 = 2,      // wn::wavenet_wg, one tile per workgroup
+    NVW_ORG_WG2 = 3,      // wn::wavenet_wg, two tiles per workgroup
+    NVW_ORG_STREAM = 4,   // wn::wavenet_stream (loader / consumer waves, 4 tiles per workgroup)
+    NVW_ORG_CHAIN = 5,    // wn::wavenet_chain, as many layers per CU as stay resident
+    NVW_ORG_CHAIN1 = 6    // wn::wavenet_chain, one layer per CU
+};
 
 template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
 class nvWavenetInfer {
@@ -53,17 +74,20 @@ public:
 protected:
     using C = wn::Cfg<F16, R, S, A, 1>;   // stream / layout constants do not depend on BT
     using SC = wn::SCfg<F16, R, S, A>;     // throughput (loader/consumer) kernel
-    static constexpr int MAXBT = 4;        // tiles are allocated in groups of 4 (one workgroup of the throughput kernel)
+    using CC = wn::CCfg<F16, R, S, A>;     // multi-CU chain
     using elem = typename wn::Prec<F16>::elem;
 
     Implementation m_implementation;
     int m_numLayers, m_maxBatch, m_maxSamples, m_maxDilation, m_tiles, m_numCUs;
-    bool m_streamMode;   // true: wn::wavenet_stream (>= 1 tile per SIMD), false: wn::wavenet_wg (lowest latency)
-    int m_forceBt;       // tiles per workgroup of wn::wavenet_wg forced by NVW_MODE=wg1|wg2 (0: by batch size)
+    int m_org;           // resolved organisation: NVW_ORG_WG1 / WG2 / WG (by batch at run time) / STREAM / CHAIN / CHAIN1
+    bool m_streamMode;   // weights / conditioning packed for wn::wavenet_stream (else: per-wave streams of wavenet_wg / chain)
+    bool m_supported;    // false: this shape does not fit the CU (run() returns false, like the reference's unsupported variants)
     int m_streamNS;      // LDS ring slots of the throughput kernel
+    int m_chainLpc, m_chainStages;   // layers per chain stage, stages (layer stages + head)
     bool m_tanhEmbed;
     int m_num_samples_per_chunk;
     int m_ringSlots;
+    int m_lastStride;    // row stride of m_yOut in the latest launch (= its num_samples)
 
     elem* m_wblob;      // packed weight fragments: L layers then the head
     float* m_bias;      // fp32 biases
@@ -72,9 +96,11 @@ protected:
     elem* m_cond;       // packed conditioning
     float* m_outputSelectors;
     elem* m_ring;
-    int m_dil[wn::kMaxLayers], m_ringOff[wn::kMaxLayers];
     int *m_yInPrev, *m_yInCur, *m_yOut;
     float *m_XtOut, *m_skipOut, *m_Zs, *m_Za, *m_p;
+    unsigned long long* m_mail;   // chain mailboxes
+    unsigned* m_chainStatus;      // [0] first time-out code of a chain launch (0 = fine)
+    size_t m_mailBytes;
 
     float* m_stage;     // device staging for fp32 uploads from host pointers
     size_t m_stageElems;
@@ -95,16 +121,26 @@ protected:
         }
         return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
     }
-    // returns a device pointer holding n floats of src (src itself when already on the device)
+    // ---- staging of fp32 host sources: every array of ONE upload call gets its own place in the
+    //      staging buffer, so the pack kernels of that call can all be in flight; the public set* calls
+    //      end with one stream synchronisation (the caller may free or reuse its buffers afterwards)
+    size_t m_stageUsed;
+    void stageBegin(size_t totalElems) {
+        if (totalElems > m_stageElems) {
+            gpuErrChk(hipStreamSynchronize(0));
+            if (m_stage) gpuErrChk(hipFree(m_stage));
+            gpuErrChk(hipMalloc(&m_stage, totalElems * sizeof(float)));
+            m_stageElems = totalElems;
+        }
+        m_stageUsed = 0;
+    }
     const float* onDevice(const float* src, size_t n) {
         if (isDevicePtr(src)) return src;
-        if (n > m_stageElems) {
-            if (m_stage) gpuErrChk(hipFree(m_stage));
-            gpuErrChk(hipMalloc(&m_stage, n * sizeof(float)));
-            m_stageElems = n;
-        }
-        gpuErrChk(hipMemcpy(m_stage, src, n * sizeof(float), hipMemcpyHostToDevice));
-        return m_stage;
+        assert(m_stageUsed + n <= m_stageElems);
+        float* d = m_stage + m_stageUsed;
+        m_stageUsed += (n + 3) & ~(size_t)3;
+        gpuErrChk(hipMemcpyAsync(d, src, n * sizeof(float), hipMemcpyHostToDevice, 0));
+        return d;
     }
     static int gridFor(size_t n) {
         size_t g = (n + 255) / 256;
@@ -118,7 +154,6 @@ protected:
                            m_wblob + blockFrag * C::FRAG_ELEMS, d, M, K, C::NW,
                            C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS, gateRT);
         gpuErrChk(hipGetLastError());
-        gpuErrChk(hipStreamSynchronize(0));
     }
     // same for the shared stream of the throughput kernel (fragment offset inside the one stream)
     void packWeightStream(size_t fragOff, const float* src, int M, int K, int rowperm, int gate = 0) {
@@ -126,13 +161,11 @@ protected:
         hipLaunchKernelGGL((wn::pack_weight_stream_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0,
                            m_wblob + fragOff * SC::FRAG_ELEMS, d, M, K, rowperm, gate);
         gpuErrChk(hipGetLastError());
-        gpuErrChk(hipStreamSynchronize(0));
     }
     void convertTo(elem* dst, const float* src, size_t n) {
         const float* d = onDevice(src, n);
         hipLaunchKernelGGL((wn::convert_kernel<F16>), dim3(gridFor(n)), dim3(256), 0, 0, dst, d, n);
         gpuErrChk(hipGetLastError());
-        gpuErrChk(hipStreamSynchronize(0));
     }
     template <int BT> static size_t ldsNeed(int L, int embTables) { return wn::Cfg<F16, R, S, A, BT>::ldsBytes(L, embTables); }
     static constexpr size_t kLdsMax = 160 * 1024;
@@ -174,15 +207,73 @@ protected:
     }
     float* headBias() { return m_bias + (size_t)m_numLayers * C::BIAS_L; }
 
+    // ---- organisation ----------------------------------------------------------------------------
+    static int chainStagesFor(int L, int lpc) { return (L + lpc - 1) / lpc + 1; }
+    // layers per stage: the fewest stages that keep every layer resident, balanced
+    static int chainLpcMax(int L) {
+        if (!CC::SUPPORTED) return 0;
+        const int ns = (L + CC::LPC - 1) / CC::LPC;
+        return (L + ns - 1) / ns;
+    }
+    bool chainFits(int lpc, int tiles) const { return lpc > 0 && chainStagesFor(m_numLayers, lpc) * tiles <= m_numCUs; }
+    bool streamFits() const { return m_streamNS >= SC::MIN_NS; }
+    // The single-workgroup organisations by batch size: up to two tiles per CU run in the latency kernel
+    // (one or two tiles split over the 4 SIMDs of a CU); beyond that every SIMD gets its own tile and the
+    // weights are streamed once per CU through an LDS ring.
+    int singleOrg(int tiles) const { return (tiles > 2 * m_numCUs && streamFits()) ? NVW_ORG_STREAM : NVW_ORG_WG; }
+    // Per-sample time models (microseconds) of the organisations that can run `tiles` tiles, from the
+    // shape: weight bytes per sample W, layers L, CUs.  Constants measured on MI355X:
+    // a CU streams 58 B/clk of weights at ~2.1 GHz beside ~0.45 us of dependent chain per layer; a chain
+    // stage costs one ~1.1 us hand-off plus ~0.5 us per layer with resident weights.
+    int pickOrganisation(int tiles) const {
+        const int single = singleOrg(tiles);
+        const int lpc = chainLpcMax(m_numLayers);
+        if (!chainFits(lpc, tiles)) return single;
+        const double wBytes = sizeof(elem) * ((double)m_numLayers * (5.0 * R * R + (double)S * R) + (double)A * S + (double)A * A);
+        const double tStream = wBytes / (58.0 * 2100.0) + 0.25 * m_numLayers + 4.0;    // us: L1 weight stream + chain + head
+        const double tChain = 1.1 * chainStagesFor(m_numLayers, lpc) + (R >= 128 ? 0.55 : 0.4) * m_numLayers + 4.0;
+        return tChain < tStream ? NVW_ORG_CHAIN : single;
+    }
+    void resolveOrganisation(int requested) {
+        const int tiles = (m_maxBatch + 15) / 16;
+        int org = requested;
+        if (org == NVW_ORG_AUTO) {
+            switch (m_implementation) {
+                case SINGLE_BLOCK: org = singleOrg(tiles); break;
+                case DUAL_BLOCK:
+                case PERSISTENT: org = chainFits(chainLpcMax(m_numLayers), tiles) ? NVW_ORG_CHAIN : singleOrg(tiles); break;
+                case MANYBLOCK_NONPERSISTENT:
+                    org = (CC::SUPPORTED && chainFits(1, tiles)) ? NVW_ORG_CHAIN1
+                          : chainFits(chainLpcMax(m_numLayers), tiles) ? NVW_ORG_CHAIN : singleOrg(tiles);
+                    break;
+                default: org = pickOrganisation(tiles); break;
+            }
+        }
+        if (org == NVW_ORG_STREAM && !streamFits()) org = NVW_ORG_WG;
+        if (org == NVW_ORG_CHAIN && !chainFits(chainLpcMax(m_numLayers), tiles)) org = singleOrg(tiles);
+        if (org == NVW_ORG_CHAIN1 && !(CC::SUPPORTED && chainFits(1, tiles))) org = singleOrg(tiles);
+        m_org = org;
+        m_streamMode = org == NVW_ORG_STREAM;
+        m_chainLpc = org == NVW_ORG_CHAIN ? chainLpcMax(m_numLayers) : org == NVW_ORG_CHAIN1 ? 1 : 0;
+        m_chainStages = m_chainLpc ? chainStagesFor(m_numLayers, m_chainLpc) : 0;
+    }
+    bool isChain() const { return m_chainLpc > 0; }
+    // tiles per workgroup of wn::wavenet_wg for a batch of `tiles` tiles
+    int wgTiles(int tiles) const {
+        const bool two = m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs);
+        return (two && ldsFits<2>()) ? 2 : 1;
+    }
+
 public:
     nvWavenetInfer(int numLayers, int maxDilation, int batchSize, int numSamples, int impl = 0,
-                   bool tanhEmbed = true)
+                   bool tanhEmbed = true, int organisation = NVW_ORG_AUTO)
         : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
-          m_num_samples_per_chunk(0), m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL),
-          m_mulaw(NULL), m_pcmUser(NULL) {
+          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0),
+          m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL), m_mulaw(NULL), m_pcmUser(NULL),
+          m_stageUsed(0) {
         assert(numLayers >= 2 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
-        m_tiles = ((batchSize + 15) / 16 + MAXBT - 1) / MAXBT * MAXBT;   // whole workgroups of MAXBT tiles
+        assert(numLayers <= wn::kMaxLayers);
         {
             int dev = 0;
             hipDeviceProp_t prop;
@@ -190,39 +281,39 @@ public:
             gpuErrChk(hipGetDeviceProperties(&prop, dev));
             m_numCUs = prop.multiProcessorCount;
         }
-
-        // dilation schedule (nv_wavenet.cuh:99,110-111): d doubles per layer, back to 1 past maxDilation
-        assert(numLayers <= wn::kMaxLayers);
-        int d = 1, slots = 0;
-        for (int l = 0; l < wn::kMaxLayers; l++) m_dil[l] = 1, m_ringOff[l] = 0;
-        for (int l = 0; l < numLayers; l++) {
-            m_dil[l] = d;
-            m_ringOff[l] = slots;
-            slots += d;
-            d <<= 1;
-            if (d > maxDilation) d = 1;
-        }
-        m_ringSlots = slots;
-
-        // kernel organisation: up to two tiles per CU run in the latency kernel (wn_kernels.hpp: one or
-        // two tiles split over the 4 SIMDs of a CU); beyond that every SIMD gets its own tile and the
-        // weights are streamed once per CU through an LDS ring (wn_stream.hpp).  NVW_MODE=stream|wg
-        // overrides (tests, experiments).
         {
             const size_t biasBytes = ((size_t)numLayers * SC::BIAS_L + 2 * A) * sizeof(float);
             long ns = ((long)kLdsMax - (long)biasBytes) / ((long)SC::CH * 1024);
             m_streamNS = (int)(ns > 6 ? 6 : ns);
-            const char* mode = getenv("NVW_MODE");
-            m_streamMode = (batchSize + 15) / 16 > 2 * m_numCUs;   // up to two tiles per CU: the latency kernel
-            m_forceBt = 0;
-            if (mode && !strcmp(mode, "stream")) m_streamMode = true;
-            if (mode && !strncmp(mode, "wg", 2)) {
-                m_streamMode = false;
-                m_forceBt = mode[2] == '1' ? 1 : mode[2] == '2' ? 2 : 0;
-            }
-            if (const char* fb = getenv("NVW_FORCE_BT")) m_forceBt = atoi(fb);   // experiments
-            if (m_streamNS < SC::MIN_NS) m_streamMode = false;
         }
+        resolveOrganisation(organisation);
+        // The bias table of the whole model lives in the LDS of a wavenet_wg workgroup: a model whose
+        // table does not fit cannot run there (the reference prints and returns false for shapes a
+        // variant does not support, nv_wavenet_singleblock.cuh:273-286)
+        m_supported = isChain() || m_streamMode || ldsFits<1>();
+        if (!m_supported)
+            fprintf(stderr, "nvWavenetInfer: R=%d S=%d A=%d with %d layers needs %zu bytes of LDS (> 160 KiB): unsupported\n", R,
+                    S, A, numLayers, ldsNeed<1>(numLayers, 0));
+
+        // conditioning / ring are allocated for whole workgroups: 4 tiles (throughput kernel), 2 (two tiles
+        // per workgroup may be chosen), else exactly the tiles of the batch
+        {
+            const int tiles = (batchSize + 15) / 16;
+            const int group = m_streamMode ? 4 : (m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs)) ? 2 : 1;
+            m_tiles = (tiles + group - 1) / group * group;
+        }
+
+        // dilation schedule (nv_wavenet.cuh:99,110-111): d doubles per layer, back to 1 past maxDilation
+        {
+            int d = 1, slots = 0;
+            for (int l = 0; l < numLayers; l++) {
+                slots += d;
+                d <<= 1;
+                if (d > maxDilation) d = 1;
+            }
+            m_ringSlots = slots;
+        }
+
         const size_t wElems = m_streamMode ? SC::streamFrags(numLayers) * SC::FRAG_ELEMS
                                            : (size_t)C::NW * C::waveStreamFrags(numLayers) * C::FRAG_ELEMS;
         gpuErrChk(hipMalloc(&m_wblob, wElems * sizeof(elem)));
@@ -261,16 +352,26 @@ public:
         gpuErrChk(hipMemset(m_Za, 0, (size_t)A * batchSize * sizeof(float)));
         gpuErrChk(hipMemset(m_p, 0, (size_t)A * batchSize * sizeof(float)));
 
+        gpuErrChk(hipMalloc(&m_chainStatus, 4 * sizeof(unsigned)));
+        gpuErrChk(hipMemset(m_chainStatus, 0, 4 * sizeof(unsigned)));
+        if (isChain()) {
+            m_mailBytes = CC::mailGranules((batchSize + 15) / 16, m_chainStages) * sizeof(unsigned long long);
+            gpuErrChk(hipMalloc(&m_mail, m_mailBytes));
+            gpuErrChk(hipMemset(m_mail, 0, m_mailBytes));
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_chain<F16, R, S, A, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::ldsBytes()));
+            if constexpr (F16)
+                gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_chain<F16, R, S, A, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::ldsBytes()));
+        }
+
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
 
-        if (!ldsFits<1>()) {
-            fprintf(stderr, "nvWavenetInfer: R=%d S=%d A=%d with %d layers needs %zu bytes of LDS (> 160 KiB)\n", R, S,
-                    A, numLayers, ldsNeed<1>(numLayers, 0));
-            exit(1);
+        if (m_supported && !isChain() && !m_streamMode) {
+            allowLds<1>();
+            allowLds<2>();
         }
-        allowLds<1>();
-        allowLds<2>();
         if (m_streamMode) {
             gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_stream<F16, R, S, A, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -300,22 +401,38 @@ public:
         gpuErrChk(hipFree(m_Zs));
         gpuErrChk(hipFree(m_Za));
         gpuErrChk(hipFree(m_p));
+        gpuErrChk(hipFree(m_chainStatus));
+        if (m_mail) gpuErrChk(hipFree(m_mail));
         if (m_stage) gpuErrChk(hipFree(m_stage));
         if (m_pcm) gpuErrChk(hipFree(m_pcm));
         if (m_mulaw) gpuErrChk(hipFree(m_mulaw));
     }
 
+    // false: the shape does not fit this GPU's CUs in the chosen organisation; run() returns false
+    bool supported() const { return m_supported; }
+    // 0 when every multi-CU launch so far ran to completion; else the code of the first hand-off that
+    // timed out (0x100+stage: x, 0x200+stage: skip sums, 0x300: head).  Synchronises the device.
+    unsigned chainStatus() {
+        unsigned s = 0;
+        gpuErrChk(hipDeviceSynchronize());
+        gpuErrChk(hipMemcpy(&s, m_chainStatus, sizeof(unsigned), hipMemcpyDeviceToHost));
+        return s;
+    }
+
     // ---- model upload: fp32 in, host or device pointers, data is copied ---------------------
     // embedPrev / embedCur: [A][R]   (nv_wavenet.cuh:396-399)
     virtual void setEmbeddings(float* embedPrev, float* embedCur) {
+        stageBegin((size_t)2 * A * R);
         convertTo(m_embedPrev, embedPrev, (size_t)A * R);
         convertTo(m_embedCur, embedCur, (size_t)A * R);
+        gpuErrChk(hipStreamSynchronize(0));
     }
     // col-major Wprev,Wcur 2RxR; Bh 2R; Wres RxR; Bres R; Wskip SxR; Bskip S (nv_wavenet.cuh:400-409)
     virtual void setLayerWeights(int layer, float* Wprev, float* Wcur, float* Bh, float* Wres, float* Bres,
                                  float* Wskip, float* Bskip) {
         assert(layer >= 0 && layer < m_numLayers);
-        const size_t lf = (size_t)layer * C::FLW;
+        stageBegin((size_t)5 * R * R + (size_t)S * R + 3 * R + S + 32);
+        float* b = m_bias + (size_t)layer * C::BIAS_L;
         if (m_streamMode) {
             const size_t sf = (size_t)layer * SC::FLP;
             packWeightStream(sf + SC::O_PREV, Wprev, 2 * R, R, 0, 1);
@@ -325,24 +442,33 @@ public:
             const size_t skipAt = (layer + 1 < m_numLayers) ? sf + SC::FLP + SC::O_SKIP
                                                             : (size_t)m_numLayers * SC::FLP + SC::H_SKIP;
             packWeightStream(skipAt, Wskip, S, R, 0);
+            gpuErrChk(hipMemcpyAsync(b, Bh, 2 * R * sizeof(float), hipMemcpyDefault, 0));
+            if constexpr (F16) {   // the fp16 gate works on pre-scaled pre-activations (wn::gate1)
+                hipLaunchKernelGGL((wn::scale_gate_bias_kernel<F16>), dim3(1), dim3(256), 0, 0, b, R);
+                gpuErrChk(hipGetLastError());
+            }
+            gpuErrChk(hipMemcpyAsync(b + 2 * R, Bres, R * sizeof(float), hipMemcpyDefault, 0));
+            gpuErrChk(hipMemcpyAsync(b + 3 * R, Bskip, S * sizeof(float), hipMemcpyDefault, 0));
         } else {
-            packWeight(lf + C::O_PREV, Wprev, 2 * R, R, C::RT);
-            packWeight(lf + C::O_CUR, Wcur, 2 * R, R, C::RT);
-            packWeight(lf + C::O_RES, Wres, R, R, 0);
-            packWeight(lf + C::O_SKIP, Wskip, S, R, 0);
-        }
-        float* b = m_bias + (size_t)layer * C::BIAS_L;
-        gpuErrChk(hipMemcpy(b, Bh, 2 * R * sizeof(float), hipMemcpyDefault));
-        if constexpr (F16) {   // the fp16 gate works on pre-scaled pre-activations (wn::gate1)
-            hipLaunchKernelGGL((wn::scale_gate_bias_kernel<F16>), dim3(1), dim3(256), 0, 0, b, R);
+            // one launch packs the four matrices and the three bias vectors of the layer
+            wn::LayerSrc src;
+            src.Wprev = onDevice(Wprev, (size_t)2 * R * R);
+            src.Wcur = onDevice(Wcur, (size_t)2 * R * R);
+            src.Bh = onDevice(Bh, 2 * R);
+            src.Wres = onDevice(Wres, (size_t)R * R);
+            src.Bres = onDevice(Bres, R);
+            src.Wskip = onDevice(Wskip, (size_t)S * R);
+            src.Bskip = onDevice(Bskip, S);
+            hipLaunchKernelGGL((wn::pack_layer_kernel<F16>), dim3(gridFor((size_t)5 * R * R + (size_t)S * R)), dim3(256), 0, 0,
+                               m_wblob + (size_t)layer * C::FLW * C::FRAG_ELEMS, b, src, R, S, C::NW,
+                               C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS, C::O_PREV, C::O_CUR, C::O_RES, C::O_SKIP);
             gpuErrChk(hipGetLastError());
-            gpuErrChk(hipStreamSynchronize(0));
         }
-        gpuErrChk(hipMemcpy(b + 2 * R, Bres, R * sizeof(float), hipMemcpyDefault));
-        gpuErrChk(hipMemcpy(b + 3 * R, Bskip, S * sizeof(float), hipMemcpyDefault));
+        gpuErrChk(hipStreamSynchronize(0));
     }
     // col-major Wzs AxS, Bzs A, Wza AxA, Bza A (nv_wavenet.cuh:410-415)
     virtual void setOutWeights(float* Wzs, float* Bzs, float* Wza, float* Bza) {
+        stageBegin((size_t)A * S + (size_t)A * A + 16);
         const size_t hf = C::headOffsetFrags(m_numLayers);
         if (m_streamMode) {
             const size_t sh = (size_t)m_numLayers * SC::FLP;
@@ -352,43 +478,66 @@ public:
             packWeight(hf, Wzs, A, S, 0);
             packWeight(hf + C::FW_ZS, Wza, A, A, 0);
         }
-        gpuErrChk(hipMemcpy(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault));
-        gpuErrChk(hipMemcpy(headBias() + A, Bza, A * sizeof(float), hipMemcpyDefault));
+        gpuErrChk(hipMemcpyAsync(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault, 0));
+        gpuErrChk(hipMemcpyAsync(headBias() + A, Bza, A * sizeof(float), hipMemcpyDefault, 0));
+        gpuErrChk(hipStreamSynchronize(0));
     }
 
     // Lh: [maxSamples][L][maxBatch][2R] conditioning, outputSelectors: [maxSamples][maxBatch]
     // uniform draws; resets the sample history to 128 (nv_wavenet.cuh:417-422).
-    void setInputs(float* Lh, float* outputSelectors) {
-        setConditioning(Lh);
+    void setInputs(float* Lh, float* outputSelectors) { setInputs(Lh, outputSelectors, m_maxSamples); }
+    // Same with numSamples <= maxSamples rows of Lh / outputSelectors (an utterance shorter than the
+    // engine's capacity: both layouts are sample-major, so a prefix is a valid input)
+    void setInputs(float* Lh, float* outputSelectors, int numSamples) {
+        setConditioning(Lh, numSamples);
         m_useRng = false;
-        gpuErrChk(hipMemcpy(m_outputSelectors, outputSelectors, (size_t)m_maxSamples * m_maxBatch * sizeof(float),
+        gpuErrChk(hipMemcpy(m_outputSelectors, outputSelectors, (size_t)numSamples * m_maxBatch * sizeof(float),
                             hipMemcpyDefault));
     }
 
     // ---- extensions beyond the reference --------------------------------
     // The conditioning half of setInputs (also resets the history to 128); pair it with
     // setSelectorSeed() and no [N][B] selector matrix is ever built or uploaded.
-    void setConditioning(float* Lh) {
-        hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
+    void setConditioning(float* Lh) { setConditioning(Lh, m_maxSamples); }
+    void setConditioning(float* Lh, int numSamples, hipStream_t stream = 0) {
+        assert(numSamples > 0 && numSamples <= m_maxSamples);
+        hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, stream, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
-        const size_t rows = (size_t)m_maxSamples * m_numLayers;
+        packConditioning(Lh, 0, numSamples, stream);
+        gpuErrChk(hipStreamSynchronize(stream));
+    }
+    // Packs samples [firstSample, firstSample + count) of the conditioning (Lh points at sample firstSample)
+    // into the engine's fragment order, asynchronously on `stream` when Lh is device memory: lets a caller
+    // stream the conditioning chunk by chunk behind run_partial() of the previous chunk.
+    void packConditioning(float* Lh, int firstSample, int count, hipStream_t stream = 0) {
+        assert(firstSample >= 0 && count > 0 && firstSample + count <= m_maxSamples);
+        const size_t rows = (size_t)count * m_numLayers;
         const size_t srcPerRow = (size_t)m_maxBatch * 2 * R;
         const size_t dstPerRow = (size_t)m_tiles * 16 * 2 * R;
+        elem* const dst0 = m_cond + (size_t)firstSample * m_numLayers * dstPerRow;
         const bool dev = isDevicePtr(Lh);
         // host sources go through the staging buffer in chunks of <= 64 Mi floats
         size_t chunkRows = dev ? rows : ((size_t)64 << 20) / srcPerRow;
         if (chunkRows < 1) chunkRows = 1;
+        if (!dev) stageBegin((chunkRows < rows ? chunkRows : rows) * srcPerRow);
         for (size_t r0 = 0; r0 < rows; r0 += chunkRows) {
             const size_t nr = (rows - r0 < chunkRows) ? rows - r0 : chunkRows;
-            const float* src = onDevice(Lh + r0 * srcPerRow, nr * srcPerRow);
+            const float* src = Lh + r0 * srcPerRow;
+            if (!dev) {
+                gpuErrChk(hipStreamSynchronize(stream));   // the previous chunk's kernel has read the staging buffer
+                gpuErrChk(hipMemcpy(m_stage, src, nr * srcPerRow * sizeof(float), hipMemcpyHostToDevice));
+                src = m_stage;
+            }
+            // one workgroup per (row, tile): 16 utterances x 2R channels, read and written coalesced
+            const size_t nblk = nr * (size_t)m_tiles;
+            const int grid = (int)(nblk > 65536 ? 65536 : nblk);
             if (m_streamMode)
-                hipLaunchKernelGGL((wn::pack_cond_stream_kernel<F16>), dim3(gridFor(nr * dstPerRow)), dim3(256), 0, 0,
-                                   m_cond + r0 * dstPerRow, src, nr, m_maxBatch, m_tiles, 2 * R);
+                hipLaunchKernelGGL((wn::pack_cond_tiled_kernel<F16, R, true>), dim3(grid), dim3(256), 0, stream,
+                                   m_cond + ((size_t)firstSample * m_numLayers + r0) * dstPerRow, src, nr, m_maxBatch, m_tiles);
             else
-                hipLaunchKernelGGL((wn::pack_cond_kernel<F16>), dim3(gridFor(nr * dstPerRow)), dim3(256), 0, 0,
-                                   m_cond + r0 * dstPerRow, src, nr, m_maxBatch, m_tiles, R, C::NW);
+                hipLaunchKernelGGL((wn::pack_cond_tiled_kernel<F16, R, false>), dim3(grid), dim3(256), 0, stream,
+                                   dst0 + r0 * dstPerRow, src, nr, m_maxBatch, m_tiles);
             gpuErrChk(hipGetLastError());
-            gpuErrChk(hipStreamSynchronize(0));
         }
     }
     // Selectors are drawn inside the kernel: Philox4x32-10, counter {sample, utterance, 0, 0}, key =
@@ -412,15 +561,18 @@ public:
                 const double signal = 2.0 * ((double)y / mu) - 1.0;
                 const double magnitude = (1.0 / mu) * (std::pow(1.0 + mu, std::fabs(signal)) - 1.0);
                 const double v = 32768.0 * (signal > 0 ? magnitude : (signal < 0 ? -magnitude : 0.0));
-                table[y] = (short)(int)v;   // truncation; the top bin wraps to -32768 like numpy's cast
+                // Truncation like numpy's astype('int16') in the reference's inference.py:58-60, INCLUDING its
+                // wrap of the top bin (y = A-1 -> +32768 -> -32768): kept on purpose, this output is pinned
+                // bit for bit to the reference's own utils.py / inference.py (tests/golden/mulaw_pcm.npz)
+                table[y] = (short)(int)v;
             }
             gpuErrChk(hipMalloc(&m_mulaw, A * sizeof(short)));
             gpuErrChk(hipMemcpy(m_mulaw, table.data(), A * sizeof(short), hipMemcpyHostToDevice));
         }
     }
     void getAudioOut(short* pcm, int offset, int size, hipStream_t stream = 0) {
-        gpuErrChk(hipMemcpy2DAsync(pcm + offset, m_maxSamples * sizeof(short), m_pcm + offset,
-                                   m_maxSamples * sizeof(short), size * sizeof(short), m_maxBatch, hipMemcpyDefault,
+        gpuErrChk(hipMemcpy2DAsync(pcm + offset, m_lastStride * sizeof(short), m_pcm + offset,
+                                   m_lastStride * sizeof(short), size * sizeof(short), m_maxBatch, hipMemcpyDefault,
                                    stream));
     }
 
@@ -429,17 +581,22 @@ public:
     void kernelInfo(int batch_size, bool dumpActivations, char* buf, int n) const {
         const int tiles = (batch_size + 15) / 16;
         const bool dump = F16 ? dumpActivations : true;
+        if (isChain()) {
+            snprintf(buf, n, "wn::wavenet_chain<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d wgs=%d lds=%zu",
+                     F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, tiles, m_chainStages * tiles,
+                     CC::ldsBytes());
+            return;
+        }
         if (m_streamMode) {
             snprintf(buf, n, "wn::wavenet_stream<%s,%d,%d,%d,DUMP=%d> tiles/wg=4 wgs=%d lds=%zu", F16 ? "fp16" : "fp32", R,
                      S, A, dump ? 1 : 0, (tiles + 3) / 4, SC::ldsBytes(m_numLayers, m_streamNS));
             return;
         }
-        const bool two = (m_forceBt ? m_forceBt == 2 : tiles > m_numCUs) && ldsFits<2>();
-        const int bt = two ? 2 : 1;
-        const int nEmb = two ? embTables<2>() : embTables<1>();
+        const int bt = wgTiles(tiles);
+        const int nEmb = bt == 2 ? embTables<2>() : embTables<1>();
         snprintf(buf, n, "wn::wavenet_wg<%s,%d,%d,%d,BT=%d,EMBLDS=%d,DUMP=%d> tiles/wg=%d wgs=%d lds=%zu",
                  F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, bt, (tiles + bt - 1) / bt,
-                 two ? ldsNeed<2>(m_numLayers, nEmb) : ldsNeed<1>(m_numLayers, nEmb));
+                 bt == 2 ? ldsNeed<2>(m_numLayers, nEmb) : ldsNeed<1>(m_numLayers, nEmb));
     }
 
     // ---- debug getters: last generated sample's activations, reference layouts --------------
@@ -454,71 +611,77 @@ public:
     void getZs(float* hZs) { gpuErrChk(hipMemcpy(hZs, m_Zs, (size_t)m_maxBatch * A * sizeof(float), hipMemcpyDefault)); }
     void getZa(float* hZa) { gpuErrChk(hipMemcpy(hZa, m_Za, (size_t)m_maxBatch * A * sizeof(float), hipMemcpyDefault)); }
     void getP(float* hP) { gpuErrChk(hipMemcpy(hP, m_p, (size_t)m_maxBatch * A * sizeof(float), hipMemcpyDefault)); }
+    // Columns [offset, offset + size) of every utterance's row, device -> caller (host or device),
+    // asynchronously on `stream` (role of nv_wavenet.cuh:439-444): the sample buffer is [batch][stride]
+    // on both sides, so this is one strided 2-D copy of `size` ints per row.
     void getYOut(int* yOut, int offset, int size, hipStream_t stream = 0) {
-        size_t cpy_pitch = m_maxSamples * sizeof(int);  // spacing between chunk first elements
-        size_t cpy_width = size * sizeof(int);          // size of individual chunk
-        size_t cpy_height = m_maxBatch;
-        gpuErrChk(hipMemcpy2DAsync(yOut + offset, cpy_pitch, m_yOut + offset, cpy_pitch, cpy_width, cpy_height,
-                                   hipMemcpyDefault, stream));
+        const size_t rowBytes = (size_t)m_lastStride * sizeof(int);
+        gpuErrChk(hipMemcpy2DAsync(yOut + offset, rowBytes, m_yOut + offset, rowBytes, (size_t)size * sizeof(int),
+                                   (size_t)m_maxBatch, hipMemcpyDefault, stream));
     }
 
     // ---- generation --------------------------------------------------------------------------
-    // Streams chunks of num_samples_per_chunk samples; the copy of chunk j overlaps the compute of
-    // chunk j+1; consume(yOut, firstSample, count) runs on the host thread per finished chunk
-    // (nv_wavenet.cuh:445-497).
+    // Generates num_samples in pieces of num_samples_per_chunk and hands every finished piece to
+    // consume(yOut, firstSample, count) on the calling thread (role of nv_wavenet.cuh:445-497).  Two
+    // streams: generation of piece k+1 is enqueued right behind piece k and never waits for the host;
+    // the device-to-caller copy of piece k runs on a second stream as soon as an event says piece k is
+    // complete, so copies and consumers overlap the generation of later pieces.  Returns after the
+    // last piece has been consumed.
     template <class Callback>
     bool run_chunks(int num_samples_per_chunk, Callback consume, int num_samples, int batch_size, int* yOut = NULL,
                     int batch_size_per_block = 1, bool dumpActivations = false, hipStream_t stream = 0) {
         (void)dumpActivations;
-        bool result = true;
-        hipStream_t stream_compute, stream_copy;
-        if (!stream) {
-            gpuErrChk(hipStreamCreate(&stream_compute));
-        } else {
-            stream_compute = stream;
+        assert(num_samples_per_chunk > 0);
+        struct Piece {
+            int first, count;
+            hipEvent_t generated, delivered;
+        };
+        std::vector<Piece> pieces;
+        for (int first = 0; first < num_samples; first += num_samples_per_chunk) {
+            Piece pc;
+            pc.first = first;
+            pc.count = num_samples - first < num_samples_per_chunk ? num_samples - first : num_samples_per_chunk;
+            gpuErrChk(hipEventCreateWithFlags(&pc.generated, hipEventDisableTiming));
+            gpuErrChk(hipEventCreateWithFlags(&pc.delivered, hipEventDisableTiming));
+            pieces.push_back(pc);
         }
-        gpuErrChk(hipStreamCreate(&stream_copy));
-        const int num_chunks = (num_samples + num_samples_per_chunk - 1) / num_samples_per_chunk;
-        std::vector<hipEvent_t> event_compute(num_chunks), event_copy(num_chunks);
-        for (int j = 0; j < num_chunks; j++) {
-            gpuErrChk(hipEventCreateWithFlags(&event_compute[j], hipEventDisableTiming));
-            gpuErrChk(hipEventCreateWithFlags(&event_copy[j], hipEventDisableTiming));
-        }
-        for (int j = 0; j < num_chunks; j++) {
-            const int initSample = j * num_samples_per_chunk;
-            const int n = (j == num_chunks - 1) ? num_samples - initSample : num_samples_per_chunk;
-            m_num_samples_per_chunk = n;
+        hipStream_t genStream = stream, outStream;
+        if (!genStream) gpuErrChk(hipStreamCreate(&genStream));
+        gpuErrChk(hipStreamCreate(&outStream));
+
+        bool ok = true;
+        for (size_t k = 0; k < pieces.size(); k++) {
+            const Piece& pc = pieces[k];
+            m_num_samples_per_chunk = pc.count;
             // The reference dumps activations in every chunk (nv_wavenet.cuh:471, hard-coded true) and
             // its test reads them back afterwards; only the last chunk's dump can be observed, so only
             // the last chunk runs the dump-capable kernel variant.
-            result = result && run_partial(initSample, num_samples, batch_size, NULL, batch_size_per_block,
-                                           j == num_chunks - 1, stream_compute);
-            gpuErrChk(hipEventRecord(event_compute[j], stream_compute));
-            gpuErrChk(hipStreamWaitEvent(stream_copy, event_compute[j], 0));
-            if (yOut != NULL) getYOut(yOut, initSample, n, stream_copy);
-            if (m_pcmUser != NULL) getAudioOut(m_pcmUser, initSample, n, stream_copy);
-            gpuErrChk(hipEventRecord(event_copy[j], stream_copy));
-        }
-        for (int j = 0; j < num_chunks; j++) {
-            const int initSample = j * num_samples_per_chunk;
-            const int n = (j == num_chunks - 1) ? num_samples - initSample : num_samples_per_chunk;
-            gpuErrChk(hipEventSynchronize(event_copy[j]));
-            consume(yOut, initSample, n);
+            ok = run_partial(pc.first, num_samples, batch_size, NULL, batch_size_per_block, k + 1 == pieces.size(), genStream) && ok;
+            gpuErrChk(hipEventRecord(pc.generated, genStream));
+            gpuErrChk(hipStreamWaitEvent(outStream, pc.generated, 0));
+            if (yOut) getYOut(yOut, pc.first, pc.count, outStream);
+            if (m_pcmUser) getAudioOut(m_pcmUser, pc.first, pc.count, outStream);
+            gpuErrChk(hipEventRecord(pc.delivered, outStream));
         }
         m_num_samples_per_chunk = 0;
-        for (int j = 0; j < num_chunks; j++) {
-            gpuErrChk(hipEventDestroy(event_compute[j]));
-            gpuErrChk(hipEventDestroy(event_copy[j]));
+        for (size_t k = 0; k < pieces.size(); k++) {
+            gpuErrChk(hipEventSynchronize(pieces[k].delivered));
+            consume(yOut, pieces[k].first, pieces[k].count);
         }
-        if (stream != stream_compute) gpuErrChk(hipStreamDestroy(stream_compute));
-        gpuErrChk(hipStreamDestroy(stream_copy));
-        return result;
+        for (size_t k = 0; k < pieces.size(); k++) {
+            gpuErrChk(hipEventDestroy(pieces[k].generated));
+            gpuErrChk(hipEventDestroy(pieces[k].delivered));
+        }
+        if (!stream) gpuErrChk(hipStreamDestroy(genStream));
+        gpuErrChk(hipStreamDestroy(outStream));
+        if (isChain() && chainStatus() != 0) ok = false;   // (everything has completed: the check costs nothing)
+        return ok;
     }
 
     // Generates samples [init_sample, init_sample + chunk) continuing from device-resident state
     // (history, dilation ring); chunk = the run_chunks chunk, or num_samples (nv_wavenet.cuh:499-635).
-    // Asynchronous on `stream`.  yOut (host or device, [maxBatch][maxSamples] ints) receives the
-    // whole sample buffer when non-NULL.
+    // Asynchronous on `stream`.  yOut (host or device, [batch][num_samples] ints) receives the
+    // sample buffer when non-NULL.
     bool run_partial(int init_sample, int num_samples, int batch_size, int* yOut = NULL, int batch_size_per_block = 1,
                      bool dumpActivations = false, hipStream_t stream = 0) {
         assert(batch_size_per_block > 0 && batch_size_per_block < 5);
@@ -526,6 +689,7 @@ public:
         assert(batch_size > 0 && batch_size <= m_maxBatch);
         assert(num_samples <= m_maxSamples);
         if (m_implementation == SINGLE_BLOCK) assert(S <= 4 * R);
+        if (!m_supported) return false;
 
         wn::Params p;
         p.wblob = m_wblob;
@@ -556,20 +720,20 @@ public:
         p.tiles = m_tiles;
         p.tanhEmbed = m_tanhEmbed ? 1 : 0;
         p.dump = dumpActivations ? 1 : 0;
-        // rings + conditioning of many tiles stream through HBM: keep them from evicting the weights
         p.embLds = 0;
         p.useRng = m_useRng ? 1 : 0;
         p.rngKey0 = (unsigned)m_rngSeed;
         p.rngKey1 = (unsigned)(m_rngSeed >> 32);
+        // rings + conditioning of many tiles stream through HBM: keep them from evicting the weights
         p.ntStream = ((size_t)((batch_size + 15) / 16) * m_ringSlots * R * 16 * sizeof(elem) > ((size_t)16 << 20)) ? 1 : 0;
+        m_lastStride = num_samples;
         if (p.count <= 0) return true;
 
-        // one tile of 16 utterances per workgroup while the CUs are not all busy (lowest latency);
-        // two tiles per workgroup share one pass over the weights beyond that
         const int tiles = (batch_size + 15) / 16;
         bool result;
-        const bool two = m_forceBt ? m_forceBt == 2 : tiles > m_numCUs;
-        if (m_streamMode) {
+        if (isChain()) {
+            result = launchChain(p, tiles, stream);
+        } else if (m_streamMode) {
             bool noDump = false;
             if constexpr (F16) noDump = !p.dump;
             if (noDump) {
@@ -581,7 +745,7 @@ public:
                                    SC::ldsBytes(m_numLayers, m_streamNS), stream, p, m_streamNS);
             }
             result = hipGetLastError() == hipSuccess;
-        } else if (two && ldsFits<2>()) result = launch<2>(p, tiles, stream);
+        } else if (wgTiles(tiles) == 2) result = launch<2>(p, tiles, stream);
         else result = launch<1>(p, tiles, stream);
         if (m_pcmUser != NULL) {
             // the indices of a finished sample are final: the expansion is a per-element map of yOut
@@ -590,10 +754,9 @@ public:
             result = result && hipGetLastError() == hipSuccess;
         }
         if (yOut != NULL) {
-            gpuErrChk(hipMemcpyAsync(yOut, m_yOut, (size_t)m_maxSamples * m_maxBatch * sizeof(int), hipMemcpyDefault,
-                                     stream));
+            gpuErrChk(hipMemcpyAsync(yOut, m_yOut, (size_t)num_samples * batch_size * sizeof(int), hipMemcpyDefault, stream));
             if (m_pcmUser != NULL)
-                gpuErrChk(hipMemcpyAsync(m_pcmUser, m_pcm, (size_t)m_maxSamples * m_maxBatch * sizeof(short),
+                gpuErrChk(hipMemcpyAsync(m_pcmUser, m_pcm, (size_t)num_samples * batch_size * sizeof(short),
                                          hipMemcpyDefault, stream));
         }
         return result;
@@ -603,5 +766,35 @@ public:
              bool dumpActivations = false, hipStream_t stream = 0) {
         m_num_samples_per_chunk = 0;
         return run_partial(0, num_samples, batch_size, yOut, batch_size_per_block, dumpActivations, stream);
+    }
+
+protected:
+    // the multi-CU chain: every (tile, stage) workgroup must be resident at the same time, so tiles are
+    // launched in groups of at most CUs / stages chains; mailboxes are re-zeroed before every launch
+    bool launchChain(wn::Params& p, int tiles, hipStream_t stream) {
+        wn::ChainParams cp;
+        cp.mail = m_mail;
+        cp.status = m_chainStatus;
+        cp.stages = m_chainStages;
+        cp.lpc = m_chainLpc;
+        p.embLds = CC::embTables();
+        const int perLaunch = m_numCUs / m_chainStages;
+        if (perLaunch < 1) return false;
+        bool dump = true;
+        if constexpr (F16) dump = p.dump != 0;
+        for (int t0 = 0; t0 < tiles; t0 += perLaunch) {
+            cp.tile0 = t0;
+            cp.chains = tiles - t0 < perLaunch ? tiles - t0 : perLaunch;
+            gpuErrChk(hipMemsetAsync(m_mail, 0, CC::mailGranules(cp.chains, m_chainStages) * sizeof(unsigned long long), stream));
+            const int grid = 8 * m_chainStages * ((cp.chains + 7) / 8);
+            if (dump) {
+                hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, true>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
+            } else {
+                if constexpr (F16)
+                    hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, false>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
+            }
+            if (hipGetLastError() != hipSuccess) return false;
+        }
+        return true;
     }
 };

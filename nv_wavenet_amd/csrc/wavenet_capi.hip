@@ -9,7 +9,7 @@
 #include "engine_base.hpp"
 
 // ---- registry of instantiations (WN_INSTANCES comes from the Makefile) ----------------------
-#define X(R, S, A, P) nvw_engine* WN_FACTORY_NAME(R, S, A, P)(int, int, int, int, int, int);
+#define X(R, S, A, P) nvw_engine* WN_FACTORY_NAME(R, S, A, P)(int, int, int, int, int, int, int);
 WN_INSTANCES
 #undef X
 
@@ -39,8 +39,8 @@ int nvw_list_supported(int* out, int max) {
     return kNumEntries;
 }
 
-nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int max_dilation, int batch_size,
-                       int num_samples, int implementation, int tanh_embed) {
+nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, int max_dilation, int batch_size,
+                          int num_samples, int implementation, int tanh_embed, int organisation) {
     const Entry* e = findEntry(R, S, A, precision);
     if (!e) {
         fprintf(stderr, "nvw_create: no nvWavenetInfer instantiation for R=%d S=%d A=%d fp%d in this build\n", R, S, A,
@@ -51,7 +51,21 @@ nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int m
         fprintf(stderr, "nvw_create: implementation %d out of range 0..4\n", implementation);
         return NULL;
     }
-    return e->make(num_layers, max_dilation, batch_size, num_samples, implementation, tanh_embed);
+    if (organisation < NVW_ORG_AUTO || organisation > NVW_ORG_CHAIN1) {
+        fprintf(stderr, "nvw_create: organisation %d out of range 0..6\n", organisation);
+        return NULL;
+    }
+    nvw_engine* w = e->make(num_layers, max_dilation, batch_size, num_samples, implementation, tanh_embed, organisation);
+    if (w && !w->supported()) {   // the shape does not fit a CU in this organisation (message already printed)
+        delete w;
+        return NULL;
+    }
+    return w;
+}
+nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int max_dilation, int batch_size,
+                       int num_samples, int implementation, int tanh_embed) {
+    return nvw_create_ex(R, S, A, precision, num_layers, max_dilation, batch_size, num_samples, implementation, tanh_embed,
+                         NVW_ORG_AUTO);
 }
 void nvw_destroy(nvw_engine* e) { delete e; }
 
@@ -63,8 +77,14 @@ void nvw_set_layer_weights(nvw_engine* e, int layer, float* Wprev, float* Wcur, 
 void nvw_set_out_weights(nvw_engine* e, float* Wzs, float* Bzs, float* Wza, float* Bza) {
     e->setOutWeights(Wzs, Bzs, Wza, Bza);
 }
-void nvw_set_inputs(nvw_engine* e, float* Lh, float* sel) { e->setInputs(Lh, sel); }
-void nvw_set_conditioning(nvw_engine* e, float* Lh) { e->setConditioning(Lh); }
+void nvw_set_inputs(nvw_engine* e, float* Lh, float* sel) { e->setInputs(Lh, sel, e->maxSamples()); }
+void nvw_set_inputs_n(nvw_engine* e, float* Lh, float* sel, int num_samples) { e->setInputs(Lh, sel, num_samples); }
+void nvw_set_conditioning(nvw_engine* e, float* Lh) { e->setConditioning(Lh, e->maxSamples()); }
+void nvw_set_conditioning_n(nvw_engine* e, float* Lh, int num_samples) { e->setConditioning(Lh, num_samples); }
+void nvw_pack_conditioning(nvw_engine* e, float* Lh, int first_sample, int count, void* stream) {
+    e->packConditioning(Lh, first_sample, count, (hipStream_t)stream);
+}
+unsigned nvw_chain_status(nvw_engine* e) { return e->chainStatus(); }
 void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed) { e->setSelectorSeed(seed); }
 void nvw_set_audio_out(nvw_engine* e, short* pcmOut) { e->setAudioOut(pcmOut); }
 void nvw_kernel_info(nvw_engine* e, int batch_size, int dump_activations, char* buf, int buf_size) {
@@ -153,7 +173,7 @@ void wavenet_infer(int sample_count, int batch_size, float* embedding_prev, floa
     // no biases on the two output layers (wavenet_infer.cu:75-82)
     std::vector<float> zeroBias(WAVENET_INFER_A, 0.f);
     w->setOutWeights(conv_out_weight, zeroBias.data(), conv_end_weight, zeroBias.data());
-    w->setInputs(cond_input, sel.data());
+    w->setInputs(cond_input, sel.data(), sample_count);
     const int bspb = ((batch_size % 4) == 0) ? 4 : ((batch_size % 2) == 0) ? 2 : 1;
     bool ok = w->run(sample_count, batch_size, samples, bspb, true, 0);
     assert(ok);

@@ -1,0 +1,689 @@
+// wn_chain.hpp -- the MULTI-CU organisation of the engine: a chain of workgroups per utterance tile,
+// every workgroup on its own CU with its share of the model RESIDENT on chip for the whole launch.
+//
+// Role of the reference's model-split variants (nv_wavenet_dualblock.cuh:99-161,289-293: layers block +
+// skip/head block; nv_wavenet_persistent.cuh:464-568: one block per layer / output role, weights held
+// in registers, blocks hand activations on through global memory).  Nothing of their structure is kept
+// (thread-per-row mat-vecs, -0.0 sentinels, volatile polling): this is a CDNA4 design.
+//
+//   * wavenet_wg (wn_kernels.hpp) streams the whole model (1.7 MB at C3, 7.2 MB at C4) through ONE CU's
+//     vector-memory path every sample; that stream, not the arithmetic, is its floor (C4: 52 us per
+//     sample > the 41.7 us of 24 kHz).  A CU can hold ~460 KB of weights: 512 registers x 64 lanes x 4
+//     waves of which ~320 per lane are free for weights (MFMA A operands straight from the register
+//     file), plus ~130 KB of LDS (ds_read_b128 per fragment, conflict-free, 4 LDS cycles against the
+//     16-cycle MFMA it feeds).  So the layer stack is cut into STAGES of lpc consecutive layers whose
+//     weights stay on chip (C3 fp16: 5 layers per CU, C4 fp16: 2), one workgroup = 4 waves per stage,
+//     plus one HEAD stage (skip ReLU -> Zs -> Za -> softmax -> pick -> embedding of the next sample).
+//     No weight is read from memory after the prologue.
+//   * A sample travels down the chain: x_l (fp32, MFMA D layout, the residual stream) from stage to
+//     stage, and behind it the running skip sums (fp32); the head closes the loop by handing the
+//     embedded next sample to stage 0.  Arithmetic, operand rounding and summation order are exactly
+//     those of wavenet_wg, so both organisations produce bit-identical samples in fp16 and fp32.
+//   * While a stage waits for the sample to arrive it does everything that does not depend on it:
+//     conditioning loads and the dilated-tap GEMMs  bias + Wprev x_l[t-d]  of all its layers
+//     (the reference's pipelined nv_wavenet_prev, nv_wavenet.cuh:87-129), so the arrival-to-departure
+//     path is  Wcur x -> gate -> Wres h  per layer only.  The skip GEMMs of a stage run after its x has
+//     left (off the critical path except in the last stage).
+//   * Hand-off = data-tagged 8-byte granules {value, tag = sample number in this launch + 1}, one
+//     agent-scope relaxed atomic store each (write-through to L2 / fabric: per-XCD L2s are not coherent
+//     and a CU's L1 is never refreshed by another CU's stores), swept by the consumer wave that needs
+//     them with agent-scope relaxed loads until every tag matches (MI355X_MICROARCH.md "handoff-1to1":
+//     ~1 us per hop; no flag, no fence, no ordering between granules needed).  Mailboxes are single
+//     slots: the autoregressive loop itself is the flow control (stage s cannot receive sample t+1
+//     before the head has finished sample t, i.e. after every stage has consumed sample t).  Mailboxes
+//     are zeroed by the host before every launch, tags count within the launch.  Every spin is bounded
+//     (wall clock); a time-out raises a status word that makes every other poller of the launch give
+//     up as well, and the host reports the launch as failed.
+//   * Placement is a speed matter only: the stages of a chain are put on one XCD (workgroup b runs on
+//     XCD b % 8 as observed on MI355X) so that granules travel through one L2.
+//
+// Layouts: weights, biases, conditioning, dilation ring, embeddings, selectors and outputs are those of
+// wavenet_wg (wn_kernels.hpp); the chain adds only the mailboxes.
+#pragma once
+
+#include "wn_kernels.hpp"
+
+namespace wn {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+struct ChainParams {
+    unsigned long long* mail;   // [chain][stage][x granules | skip granules], zeroed before every launch
+    unsigned* status;           // [0]: 0 = fine, else the code of the first time-out (host checks after the launch)
+    int stages;                 // layer stages + 1 (head)
+    int lpc;                    // layers per layer stage (<= CCfg::LPC)
+    int chains;                 // utterance tiles of this launch
+    int tile0;                  // first tile (chains of one launch cover tiles tile0 .. tile0+chains-1)
+};
+
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+
+template <bool F16, int R, int S, int A>
+struct CCfg {
+    using C = Cfg<F16, R, S, A, 1>;
+    static constexpr int NW = C::NW, FLW = C::FLW, FHW = C::FHW;
+    static constexpr int LDS_MAX = 160 * 1024;
+    static constexpr int REG_FRAGS = 80;                   // weight fragments a wave keeps in registers (320 of 512)
+    static constexpr int MAX_LPC = 8;
+    // ---- layer stage with n layers: x image | n h images | n x (biases + running skip bias) | weights ----
+    static constexpr int fixedLds(int n) { return C::XBUF + n * C::HBUF + n * (C::BIAS_L + S) * 4; }
+    static constexpr int ldsFrags(int n) {                // fragments per layer per wave that live in LDS
+        int avail = (LDS_MAX - fixedLds(n)) / (n * NW * 1024);
+        return avail < 0 ? 0 : (avail > FLW ? FLW : avail);
+    }
+    static constexpr bool fits(int n) { return LDS_MAX > fixedLds(n) && (FLW - ldsFrags(n)) * n <= REG_FRAGS; }
+    static constexpr int pickLpc() {
+        int best = 0;
+        for (int n = 1; n <= MAX_LPC; n++)
+            if (fits(n)) best = n;
+        return best;
+    }
+    static constexpr int LPC = pickLpc();                  // 0: not even one layer fits a CU (no chain for this shape)
+    static constexpr bool SUPPORTED = LPC > 0;
+    static constexpr int LP = LPC > 0 ? LPC : 1;
+    static constexpr int NLD = ldsFrags(LP);               // fragments per layer per wave in LDS (the tail of the layer stream)
+    static constexpr int NRG = FLW - NLD;                  // ... in registers (the head of the layer stream)
+    static constexpr int OFF_LX = 0, OFF_LH = C::XBUF, OFF_LB = OFF_LH + LP * C::HBUF;
+    static constexpr int OFF_LW = (OFF_LB + LP * (C::BIAS_L + S) * 4 + 15) & ~15;
+    static constexpr int LAYER_LDS = OFF_LW + LP * NW * NLD * 1024;
+    // ---- head stage: skip image | zs image | logits | picks | biases (final skip bias, Bzs, Bza) | embeddings ----
+    // the head's weights stay in registers when they fit (64 fragments at C3 / C4), else they are streamed
+    // through the prefetch ring like wavenet_wg does (large A, fp32)
+    static constexpr int HEADREGS = 288;
+    static constexpr int HR = FHW * 4 <= HEADREGS ? FHW : (C::FW_ZA * 4 <= HEADREGS ? C::FW_ZA : 0);
+    static constexpr int HS = FHW - HR;
+    static constexpr int OFF_HSK = 0, OFF_HZS = C::SKBUF;
+    static constexpr int OFF_HLG = C::ALIAS_LG ? OFF_HZS : OFF_HZS + C::ZSBUF;
+    static constexpr int OFF_HY = C::ALIAS_LG ? OFF_HZS + (C::ZSBUF > C::LGBUF ? C::ZSBUF : C::LGBUF) : OFF_HLG + C::LGBUF;
+    static constexpr int OFF_HB = OFF_HY + C::YBUF;
+    static constexpr int OFF_HE = (OFF_HB + (S + 2 * A) * 4 + 15) & ~15;
+    static size_t headLds(int embTables) { return (size_t)OFF_HE + (size_t)embTables * A * R * sizeof(typename C::P::elem); }
+    static int embTables() { return headLds(2) <= (size_t)LDS_MAX ? 2 : headLds(1) <= (size_t)LDS_MAX ? 1 : 0; }
+    static size_t ldsBytes() {
+        const size_t h = headLds(embTables());
+        return h > (size_t)LAYER_LDS ? h : (size_t)LAYER_LDS;
+    }
+    // mailboxes of one stage, in granules
+    static constexpr int XG = R * 16, SG = S * 16;
+    static constexpr size_t mailGranules(int chains, int stages) { return (size_t)chains * stages * (XG + SG); }
+};
+
+// Experiment build (-DWN_CHAIN_TIMING): wave 0 of every stage stamps the 100 MHz wall clock (one counter for
+// the whole chip) at its phase boundaries for samples 8..15 of the launch into p.p, read as
+// unsigned long long [stage][8 samples][16 events] (scripts/chain_phase.py).
+#ifdef WN_CHAIN_TIMING
+#define WN_CT_DECL unsigned long long cts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WN_CT(ev) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); cts[ev] = __builtin_amdgcn_s_memrealtime(); }
+#define WN_CT_FLUSH(stageIdx, tt)                                                                           \
+    if (w == 0 && lane == 0 && (tt) >= 8 && (tt) < 16) {                                                      \
+        unsigned long long* dbg = (unsigned long long*)p.p + ((size_t)(stageIdx) * 8 + ((tt) - 8)) * 16;      \
+        _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) dbg[q_] = cts[q_];                                 \
+    }
+#else
+#define WN_CT_DECL
+#define WN_CT(ev) {}
+#define WN_CT_FLUSH(stageIdx, tt) {}
+#endif
+
+// ---- hand-off primitives -----------------------------------------------------------------------
+#ifndef WN_CHAIN_TIMEOUT_TICKS
+#define WN_CHAIN_TIMEOUT_TICKS 150000000LL     // 1.5 s of the 100 MHz wall clock
+#endif
+
+struct Spin {
+    gu32* status;
+    long long t0;
+    unsigned spins;
+};
+// false: give up (this wave timed out, or another one did)
+WN_DEV bool spin_more(Spin& s, unsigned code) {
+    if ((++s.spins & 127u) == 0u) {
+        if (__hip_atomic_load(s.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        if ((long long)wall_clock64() - s.t0 > WN_CHAIN_TIMEOUT_TICKS) {
+            __hip_atomic_store(s.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    __builtin_amdgcn_s_sleep(1);
+    return true;
+}
+
+// tile `tile`, register r of lane `lane`: granule index inside a mailbox (lanes contiguous: one 512-byte
+// coalesced access per wave instruction)
+WN_DEV int granule_at(int tile, int r, int lane) { return (tile * 4 + r) * 64 + lane; }
+
+// this wave's tiles w, w+NW, ... of a vector in MFMA D layout -> the consumer's mailbox
+template <int NT, int NW>
+WN_DEV void send_tiles(unsigned long long* mbox, int w, int lane, unsigned tag, const floatx4 (&v)[NT]) {
+    gu64* g = (gu64*)mbox;
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            // (through a scalar: __builtin_bit_cast applied to the vector-element lvalue v[i][r] itself reads element 0)
+            const float f = v[i][r];
+            __hip_atomic_store(g + granule_at(w + NW * i, r, lane), ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(f),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+}
+// the same tiles, swept until every granule carries `tag`
+template <int NT, int NW>
+WN_DEV bool recv_tiles(const unsigned long long* mbox, int w, int lane, unsigned tag, floatx4 (&v)[NT], gu32* status,
+                       unsigned code) {
+    gu64* g = (gu64*)mbox;
+    Spin s{status, (long long)wall_clock64(), 0u};
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const unsigned long long x =
+                    __hip_atomic_load(g + granule_at(w + NW * i, r, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[i][r] = __uint_as_float((unsigned)x);
+                ok &= (unsigned)(x >> 32) == tag;
+            }
+        if (__all(ok)) return true;
+        if (!spin_more(s, code)) return false;
+    }
+}
+
+// acc[mt] += W(tile slot mt) * b   with the stage's resident weights: fragment idx of the layer stream
+// sits in registers when idx < NRG, else in this wave's LDS slice (same order as gemm(), wn_kernels.hpp)
+template <bool F16, int NRG, int POS0, int MT, int KF>
+WN_DEV void gemm_rs(const typename Prec<F16>::frag (&wr)[NRG ? NRG : 1], const char* wl, unsigned laneOff, floatx4 (&acc)[MT],
+                    const typename Prec<F16>::frag (&b)[KF]) {
+    using frag = typename Prec<F16>::frag;
+    constexpr int G = MT >= 4 ? 4 : MT;
+#pragma unroll
+    for (int mg = 0; mg < MT / G; mg++)
+#pragma unroll
+        for (int kf = 0; kf < KF; kf++)
+#pragma unroll
+            for (int mi = 0; mi < G; mi++) {
+                const int idx = POS0 + (mg * KF + kf) * G + mi;
+                frag a;
+                if (idx < NRG) a = wr[idx < NRG ? idx : 0];
+                else a = *(const frag*)(wl + (size_t)(idx - NRG) * 1024 + laneOff);
+                acc[mg * G + mi] = mma(a, b[kf], acc[mg * G + mi]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer stage: layers l0 .. l0+nl-1 of tile `tile`
+// ------------------------------------------------------------------------------------------------
+template <bool F16, int R, int S, int A, bool DUMP>
+WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int tile, int chainIdx, int stage) {
+    using CC = CCfg<F16, R, S, A>;
+    using C = typename CC::C;
+    using P = Prec<F16>;
+    using frag = typename P::frag;
+    using elem = typename P::elem;
+    constexpr int LP = CC::LP, NRG = CC::NRG, NLD = CC::NLD, NW = C::NW, FLW = C::FLW;
+    constexpr int RT = C::RT, HTW = C::HTW, STW = C::STW, KF_R = C::KF_R;
+
+    char* const xbuf = lds + CC::OFF_LX;
+    char* const hbuf = lds + CC::OFF_LH;
+    float* const biasLds = (float*)(lds + CC::OFF_LB);          // [LP][BIAS_L] then [LP][S] running skip bias
+    float* const rsb = biasLds + LP * C::BIAS_L;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int L = p.numLayers;
+    const int l0 = stage * cp.lpc;
+    const int nl = cmin(cp.lpc, L - l0);
+    const bool lastLayerStage = stage == cp.stages - 2;
+    const unsigned laneOff = (unsigned)lane * 16u;
+    char* const wlds = lds + CC::OFF_LW + (size_t)w * LP * NLD * 1024;     // this wave's slice
+
+    const int b = tile * 16 + j;
+    const bool uvalid = b < p.batch;
+    const int ub = uvalid ? b : p.batch - 1;
+
+    // mailboxes: this stage's inputs, the next stage's inputs
+    unsigned long long* const mbase = cp.mail + ((size_t)chainIdx * cp.stages + stage) * (CC::XG + CC::SG);
+    const unsigned long long* const xin = mbase;
+    const unsigned long long* const skin = mbase + CC::XG;
+    unsigned long long* const xout = mbase + (CC::XG + CC::SG);
+    unsigned long long* const skout = xout + CC::XG;
+    gu32* const status = (gu32*)cp.status;
+
+    // ---- biases of the own layers -> LDS; running skip-bias sums (dump only) ---------------------
+    for (int i = tid; i < nl * C::BIAS_L; i += C::THREADS) biasLds[i] = p.bias[(size_t)l0 * C::BIAS_L + i];
+    if (DUMP) {
+        for (int s0 = tid; s0 < S; s0 += C::THREADS) {
+            float run = 0.f;
+            for (int l = 0; l < l0 + nl; l++) {
+                const float bl = p.bias[(size_t)l * C::BIAS_L + 3 * R + s0];
+                run = l == 0 ? bl : run + bl;                  // layer order, like wavenet_wg
+                if (l >= l0) rsb[(l - l0) * S + s0] = run;
+            }
+        }
+    }
+
+    // ---- resident weights: head of every layer's stream -> registers, tail -> this wave's LDS slice ----
+    const char* const wbase = (const char*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 1024;
+    frag wr[LP][NRG ? NRG : 1];
+#pragma unroll
+    for (int li = 0; li < LP; li++) {
+        const char* wl = wbase + (size_t)(l0 + (li < nl ? li : 0)) * FLW * 1024;
+#pragma unroll
+        for (int i = 0; i < NRG; i++) wr[li][i] = *(const frag*)(wl + (size_t)i * 1024 + laneOff);
+        if (li < nl) {
+#pragma unroll
+            for (int i = 0; i < NLD; i++)
+                *(frag*)(wlds + (size_t)(li * NLD + i) * 1024 + laneOff) = *(const frag*)(wl + (size_t)(NRG + i) * 1024 + laneOff);
+        }
+    }
+
+    // dilation and first ring slot of the own layers
+    Dil dl[LP];
+    {
+        Dil s = dil_first();
+        for (int l = 0; l < l0; l++) s = dil_next(s, p.maxDilation, false);
+#pragma unroll
+        for (int li = 0; li < LP; li++) {
+            dl[li] = s;
+            s = dil_next(s, p.maxDilation, false);
+        }
+    }
+    const size_t condStride = (size_t)p.tiles * NW * C::COND_FR * 1024;             // one (sample, layer) row
+    const char* const condMine = (const char*)p.cond + ((size_t)tile * NW + w) * C::COND_FR * 1024;
+    const size_t ringTile = (size_t)p.ringSlots * KF_R * 1024;
+    char* const ringMine = (char*)p.ring + (size_t)tile * ringTile;
+
+    frag selA[P::TPF];
+#pragma unroll
+    for (int tt = 0; tt < P::TPF; tt++)
+#pragma unroll
+        for (int e = 0; e < P::EPL; e++) selA[tt][e] = (elem)(((e >> 2) == tt && g * 4 + (e & 3) == j) ? 1.0f : 0.0f);
+
+    const int tEnd = p.initSample + p.count;
+    for (int t = p.initSample; t < tEnd; t++) {
+        const unsigned tag = (unsigned)(t - p.initSample) + 1u;
+        const bool dumpNow = DUMP && p.dump && (t == tEnd - 1);
+        // every ring store of the previous sample has completed (and is visible to the whole workgroup:
+        // one L1 per CU); also orders the reuse of the h images and of the bias table after the prologue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier();
+        WN_CT_DECL
+        WN_CT(0)
+
+        // ---- while the sample is on its way: conditioning + dilated-tap GEMMs of all own layers ------
+        floatx4 acc[LP][2 * HTW];
+        frag cd[LP][C::COND_FR];
+#pragma unroll
+        for (int li = 0; li < LP; li++) {
+            if (li < nl) {
+                const int l = l0 + li;
+                const float* bl = biasLds + li * C::BIAS_L;
+                const char* cp0 = condMine + ((size_t)t * L + l) * condStride;
+#pragma unroll
+                for (int k = 0; k < C::COND_FR; k++) cd[li][k] = *(const frag*)(cp0 + k * 1024 + laneOff);
+#pragma unroll
+                for (int i = 0; i < HTW; i++) {
+                    acc[li][2 * i] = *(const floatx4*)(bl + (w + NW * i) * 16 + g * 4);
+                    acc[li][2 * i + 1] = *(const floatx4*)(bl + (w + NW * i + RT) * 16 + g * 4);
+                }
+                const int d = dl[li].d;
+                const bool havePrev = t >= d;
+                frag xp[KF_R];
+                const char* rp = ringMine + (size_t)(unsigned)(dl[li].off + (t & (d - 1))) * (KF_R * 1024);
+#pragma unroll
+                for (int k = 0; k < KF_R; k++) {
+                    if (havePrev) xp[k] = *(const frag*)(rp + (size_t)k * 1024 + laneOff);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < P::EPL; e++) xp[k][e] = (elem)0.f;
+                    }
+                }
+                gemm_rs<F16, NRG, C::O_PREV, 2 * HTW, KF_R>(wr[li], wlds + (size_t)li * NLD * 1024, laneOff, acc[li], xp);
+            }
+        }
+
+        // ---- the sample arrives: x_l0[t], this wave's tiles (fp32) ----------------------------------
+        floatx4 x[HTW];
+        WN_CT(1)
+        if (!recv_tiles<HTW, NW>(xin, w, lane, tag, x, status, 0x100u + (unsigned)stage)) return;
+        WN_CT(2)
+#pragma unroll
+        for (int i = 0; i < HTW; i++) lds_put_tile<F16>(xbuf, w + NW * i, lane, x[i]);
+        wg_barrier();
+
+#pragma unroll
+        for (int li = 0; li < LP; li++) {
+            if (li < nl) {
+                const int l = l0 + li;
+                const float* bl = biasLds + li * C::BIAS_L;
+                const char* wl = wlds + (size_t)li * NLD * 1024;
+                char* const hb_img = hbuf + li * C::HBUF;
+                frag xb[KF_R];
+                lds_get_frags<F16, KF_R>(xbuf, lane, xb);
+                if (li == 0) WN_CT(8)
+                // x_l[t] replaces x_l[t-d] in the ring (each wave stores its share of the fragments)
+                {
+                    const int d = dl[li].d;
+                    char* rp = ringMine + (size_t)(unsigned)(dl[li].off + (t & (d - 1))) * (KF_R * 1024);
+#pragma unroll
+                    for (int k = 0; k < KF_R; k++)
+                        if (k % NW == w) *(frag*)(rp + (size_t)k * 1024 + laneOff) = xb[k];
+                }
+                gemm_rs<F16, NRG, C::O_CUR, 2 * HTW, KF_R>(wr[li], wl, laneOff, acc[li], xb);
+                if constexpr (F16) {
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                        for (int tt = 0; tt < P::TPF; tt++)
+                            acc[li][k * P::TPF + tt] = mma(selA[tt], cd[li][k], acc[li][k * P::TPF + tt]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                        for (int e = 0; e < P::EPL; e++) acc[li][k * P::TPF + (e >> 2)][e & 3] += (float)cd[li][k][e];
+                }
+                if (li == 0) {
+                    asm volatile("s_nop 0" ::"v"(acc[li][0][0]), "v"(acc[li][1][0]));
+                    WN_CT(9)
+                }
+#pragma unroll
+                for (int i = 0; i < HTW; i++) {
+                    const floatx4 hv = gate4<F16>(acc[li][2 * i], acc[li][2 * i + 1]);
+                    lds_put_tile<F16>(hb_img, w + NW * i, lane, hv);
+                }
+                if (li == 0) WN_CT(10)
+                wg_barrier();   // h complete
+                if (li == 0) WN_CT(11)
+                frag hb[KF_R];
+                lds_get_frags<F16, KF_R>(hb_img, lane, hb);
+                if (li == 0) WN_CT(12)
+                floatx4 xa[HTW];
+#pragma unroll
+                for (int i = 0; i < HTW; i++) xa[i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[i];
+                gemm_rs<F16, NRG, C::O_RES, HTW, KF_R>(wr[li], wl, laneOff, xa, hb);
+#pragma unroll
+                for (int i = 0; i < HTW; i++) x[i] = xa[i];
+                if (li == 0) {
+                    asm volatile("s_nop 0" ::"v"(x[0][0]));
+                    WN_CT(13)
+                }
+                if (dumpNow && uvalid) {
+#pragma unroll
+                    for (int i = 0; i < HTW; i++)
+                        *(floatx4*)(p.xtOut + ((size_t)l * p.maxBatch + ub) * R + (w + NW * i) * 16 + g * 4) = x[i];
+                }
+                if (li + 1 < nl) {   // the next own layer reads x through LDS; the last one hands it on
+#pragma unroll
+                    for (int i = 0; i < HTW; i++) lds_put_tile<F16>(xbuf, w + NW * i, lane, x[i]);
+                    wg_barrier();   // x complete
+                    if (li == 0) WN_CT(14)
+                }
+            }
+        }
+        WN_CT(3)
+        if (!lastLayerStage) send_tiles<HTW, NW>(xout, w, lane, tag, x);   // (the last layer's output is unused)
+        WN_CT(4)
+
+        // ---- behind the sample: running skip sums  skip <- Wskip_l h_l + skip  ------------------------
+        floatx4 sk[STW];
+        if (stage == 0) {
+#pragma unroll
+            for (int i = 0; i < STW; i++) sk[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        } else if (!recv_tiles<STW, NW>(skin, w, lane, tag, sk, status, 0x200u + (unsigned)stage)) return;
+        WN_CT(5)
+#pragma unroll
+        for (int li = 0; li < LP; li++) {
+            if (li < nl) {
+                frag hb[KF_R];
+                lds_get_frags<F16, KF_R>(hbuf + li * C::HBUF, lane, hb);
+                gemm_rs<F16, NRG, C::O_SKIP, STW, KF_R>(wr[li], wlds + (size_t)li * NLD * 1024, laneOff, sk, hb);
+                // (the last layer's skipOut is dumped by the head, after the ReLU)
+                if (dumpNow && uvalid && l0 + li < L - 1) {
+                    const float* bp = rsb + li * S;
+#pragma unroll
+                    for (int i = 0; i < STW; i++)
+                        *(floatx4*)(p.skipOut + ((size_t)(l0 + li) * p.maxBatch + ub) * S + (w + NW * i) * 16 + g * 4) =
+                            sk[i] + *(const floatx4*)(bp + (w + NW * i) * 16 + g * 4);
+                }
+            }
+        }
+        WN_CT(6)
+        send_tiles<STW, NW>(skout, w, lane, tag, sk);
+        WN_CT(7)
+        WN_CT_FLUSH(stage, t - p.initSample)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head stage: final skip -> Zs -> Za -> softmax -> pick -> embedding of the next sample
+// ------------------------------------------------------------------------------------------------
+template <bool F16, int R, int S, int A, bool DUMP>
+WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int tile, int chainIdx) {
+    using CC = CCfg<F16, R, S, A>;
+    using C = typename CC::C;
+    using P = Prec<F16>;
+    using frag = typename P::frag;
+    using quad = typename P::quad;
+    using elem = typename P::elem;
+    constexpr int NW = C::NW, PF = C::PF;
+    constexpr int HTW = C::HTW, STW = C::STW, ATW = C::ATW;
+    constexpr int KF_S = C::KF_S, KF_A = C::KF_A;
+    constexpr int HR = CC::HR, HS = CC::HS;
+
+    char* const skbuf = lds + CC::OFF_HSK;
+    char* const zsbuf = lds + CC::OFF_HZS;
+    float* const lgbuf = (float*)(lds + CC::OFF_HLG);
+    int* const ybuf = (int*)(lds + CC::OFF_HY);
+    float* const fsb = (float*)(lds + CC::OFF_HB);           // final running skip bias [S], then Bzs[A], Bza[A]
+    float* const headBias = fsb + S;
+    elem* const embLds = (elem*)(lds + CC::OFF_HE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int L = p.numLayers;
+    const int stage = cp.stages - 1;
+    const unsigned laneOff = (unsigned)lane * 16u;
+
+    const int b = tile * 16 + j;
+    const bool uvalid = b < p.batch;
+    const int ub = uvalid ? b : p.batch - 1;
+    const int su = tid / C::LPU, sq = tid % C::LPU;            // softmax role
+
+    unsigned long long* const mbase = cp.mail + ((size_t)chainIdx * cp.stages + stage) * (CC::XG + CC::SG);
+    const unsigned long long* const skin = mbase + CC::XG;
+    unsigned long long* const xout = cp.mail + ((size_t)chainIdx * cp.stages) * (CC::XG + CC::SG);   // stage 0
+    gu32* const status = (gu32*)cp.status;
+
+    // ---- biases: sum of all skip biases (layer order, like wavenet_wg's running sums), Bzs, Bza ----
+    for (int s0 = tid; s0 < S; s0 += C::THREADS) {
+        float run = p.bias[3 * R + s0];
+        for (int l = 1; l < L; l++) run += p.bias[(size_t)l * C::BIAS_L + 3 * R + s0];
+        fsb[s0] = run;
+    }
+    for (int i = tid; i < 2 * A; i += C::THREADS) headBias[i] = p.bias[(size_t)L * C::BIAS_L + i];
+    // ---- embedding tables -> LDS (p.embLds = 2: both, 1: the current tap's only) ------------------
+    const int nEmb = p.embLds;
+    if (nEmb > 0) {
+        const floatx4* s0 = (const floatx4*)p.embCur;
+        const floatx4* s1 = (const floatx4*)p.embPrev;
+        constexpr int CH = (int)(A * R * sizeof(elem) / 16);
+        for (int i = tid; i < CH; i += C::THREADS) {
+            ((floatx4*)embLds)[i] = s0[i];
+            if (nEmb > 1) ((floatx4*)embLds)[CH + i] = s1[i];
+        }
+    }
+    const elem* const gEmbPrev = (const elem*)p.embPrev;
+    const elem* const gEmbCur = (const elem*)p.embCur;
+    auto rowCur = [&](int y, int tile16) -> floatx4 {
+        const size_t off = (size_t)y * R + tile16 * 16 + g * 4;
+        if (nEmb > 0) return quad_to_f32(*(const quad*)(embLds + off));
+        return quad_to_f32(*(const quad*)(gEmbCur + off));
+    };
+    auto rowPrev = [&](int y, int tile16) -> floatx4 {
+        const size_t off = (size_t)y * R + tile16 * 16 + g * 4;
+        if (nEmb > 1) return quad_to_f32(*(const quad*)(embLds + (size_t)A * R + off));
+        return quad_to_f32(*(const quad*)(gEmbPrev + off));
+    };
+
+    // ---- head weights: resident fragments, prefetch ring for the streamed part ---------------------
+    const char* const wbase = (const char*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 1024;
+    const char* const whead = wbase + C::headOffsetFrags(L) * 1024;
+    frag hw[HR ? HR : 1];
+    if constexpr (HR > 0) {
+#pragma unroll
+        for (int i = 0; i < HR; i++) hw[i] = *(const frag*)(whead + (size_t)(HS + i) * 1024 + laneOff);
+    }
+    WStream<F16, PF> ws;
+    if constexpr (HS > 0) {
+        static_assert(HS >= PF, "streamed head shorter than the prefetch ring");
+#pragma unroll
+        for (int i = 0; i < PF; i++) ws.buf[i] = *(const frag*)(whead + (size_t)i * 1024 + laneOff);
+    }
+
+    int yPrev = p.yInPrev[ub], yCur = p.yInCur[ub];
+    __syncthreads();   // tables and biases complete
+
+    // embedding of the sample after (yPrev, yCur) -> stage 0 (nv_wavenet_reference.cpp:42-56)
+    auto embed_and_send = [&](unsigned tag) {
+        floatx4 x0[HTW];
+#pragma unroll
+        for (int i = 0; i < HTW; i++) {
+            const int tile16 = w + NW * i;
+            floatx4 v = rowPrev(yPrev, tile16) + rowCur(yCur, tile16);
+            if (p.tanhEmbed) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = tanh_t<F16>(v[r]);
+            }
+            x0[i] = v;
+        }
+        send_tiles<HTW, NW>(xout, w, lane, tag, x0);
+    };
+    embed_and_send(1u);
+
+    const int tEnd = p.initSample + p.count;
+    for (int t = p.initSample; t < tEnd; t++) {
+        const unsigned tag = (unsigned)(t - p.initSample) + 1u;
+        const bool dumpNow = DUMP && p.dump && (t == tEnd - 1);
+        int sb = tile * 16 + su;
+        const bool sbValid = sb < p.batch;
+        sb = sbValid ? sb : p.batch - 1;
+        const float selv = p.useRng ? philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)sb)
+                                    : p.sel[(size_t)t * p.maxBatch + sb];
+
+        // ---- skip sums of all layers arrive; + biases, ReLU -> B fragments -----------------------------
+        floatx4 sk[STW];
+        WN_CT_DECL
+        WN_CT(0)
+        if (!recv_tiles<STW, NW>(skin, w, lane, tag, sk, status, 0x300u)) return;
+        WN_CT(1)
+#pragma unroll
+        for (int i = 0; i < STW; i++) {
+            floatx4 v = sk[i] + *(const floatx4*)(fsb + (w + NW * i) * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
+            lds_put_tile<F16>(skbuf, w + NW * i, lane, v);
+            if (dumpNow && uvalid)   // the oracle applies the ReLU to the last layer's skipOut in place
+                *(floatx4*)(p.skipOut + ((size_t)(L - 1) * p.maxBatch + ub) * S + (w + NW * i) * 16 + g * 4) = v;
+        }
+        wg_barrier();
+        floatx4 zs[1][ATW];
+        {
+            frag sbf[1][KF_S];
+            lds_get_frags<F16, KF_S>(skbuf, lane, sbf[0]);
+#pragma unroll
+            for (int i = 0; i < ATW; i++) zs[0][i] = *(const floatx4*)(headBias + (w + NW * i) * 16 + g * 4);
+            if constexpr (HS == 0) gemm_res<F16, 1, ATW, KF_S>(hw, 0, zs, sbf);
+            else gemm<F16, PF, HS, 1, ATW, KF_S>(ws, 0, whead, whead, laneOff, zs, sbf);
+        }
+#pragma unroll
+        for (int i = 0; i < ATW; i++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) zs[0][i][r] = __builtin_fmaxf(zs[0][i][r], 0.f);
+            lds_put_tile<F16>(zsbuf, w + NW * i, lane, zs[0][i]);
+            if (dumpNow && uvalid) *(floatx4*)(p.zs + (size_t)ub * A + (w + NW * i) * 16 + g * 4) = zs[0][i];
+        }
+        wg_barrier();
+        {
+            floatx4 za[1][ATW];
+#pragma unroll
+            for (int i = 0; i < ATW; i++) za[0][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
+            if constexpr (C::ZA_B_FROM_LDS) {
+                static_assert(HR == 0, "the LDS-streamed head is for the large, non-resident heads");
+                gemm_ldsb<F16, PF, HS, 1, ATW, KF_A>(ws, C::FW_ZS, whead, whead, laneOff, za, zsbuf, lane);
+            } else {
+                frag zb[1][KF_A];
+                lds_get_frags<F16, KF_A>(zsbuf, lane, zb[0]);
+                if constexpr (HR >= C::FW_ZA) gemm_res<F16, 1, ATW, KF_A>(hw, C::FW_ZS - HS, za, zb);
+                else gemm<F16, PF, HS, 1, ATW, KF_A>(ws, C::FW_ZS, whead, whead, laneOff, za, zb);
+            }
+            if constexpr (C::ALIAS_LG) wg_barrier();   // every wave is done with the zs image
+#pragma unroll
+            for (int i = 0; i < ATW; i++) {
+                *(floatx4*)(lgbuf + j * C::LROW + (w + NW * i) * 16 + g * 4) = za[0][i];
+                if (dumpNow && uvalid) *(floatx4*)(p.za + (size_t)ub * A + (w + NW * i) * 16 + g * 4) = za[0][i];
+            }
+        }
+        // the streamed part of the head is not a multiple of the ring: rotate the ring back into phase
+        if constexpr (HS > 0 && HS % PF != 0) {
+            frag tmp[PF];
+#pragma unroll
+            for (int i = 0; i < PF; i++) tmp[i] = ws.buf[(i + HS) % PF];
+#pragma unroll
+            for (int i = 0; i < PF; i++) ws.buf[i] = tmp[i];
+        }
+        wg_barrier();
+        WN_CT(2)
+
+        // ---- softmax + pick ------------------------------------------------------------------------
+        {
+            float e[C::RPL];
+            float total;
+            const int pick = softmax_pick<A, C::LPU, C::RPL>(lgbuf + su * C::LROW + sq * C::RPL, sq, lane, selv, e, total);
+            if (sq == 0) {
+                ybuf[su] = pick;
+                if (sbValid) p.yOut[(size_t)sb * p.numSamples + t] = pick;
+            }
+            if (dumpNow && sbValid) {
+                const float inv = 1.0f / total;
+#pragma unroll
+                for (int i = 0; i < C::RPL / 4; i++)
+                    *(floatx4*)(p.p + (size_t)sb * A + sq * C::RPL + i * 4) =
+                        floatx4{e[i * 4] * inv, e[i * 4 + 1] * inv, e[i * 4 + 2] * inv, e[i * 4 + 3] * inv};
+            }
+        }
+        wg_barrier();
+        WN_CT(3)
+        yPrev = yCur;
+        yCur = ybuf[j];
+        if (t + 1 < tEnd) embed_and_send(tag + 1u);
+        WN_CT(4)
+        WN_CT_FLUSH(stage, t - p.initSample)
+        // ybuf / lgbuf / skbuf are next written after the next sample's barriers
+    }
+    if (w == 0 && g == 0 && uvalid) {
+        p.yInPrev[ub] = yPrev;
+        p.yInCur[ub] = yCur;
+    }
+}
+
+// One workgroup per (tile, stage).  Workgroup b is observed to run on XCD b % 8: the stages of a chain
+// take workgroups of one residue class so that a chain's granules stay in one L2 (speed only).
+template <bool F16, int R, int S, int A, bool DUMP>
+__global__ __launch_bounds__((Cfg<F16, R, S, A, 1>::THREADS), 1) void wavenet_chain(const Params p, const ChainParams cp) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if constexpr (!CCfg<F16, R, S, A>::SUPPORTED) return;   // not even one layer fits a CU: never launched
+    const int bidx = blockIdx.x;
+    const int xcd = bidx & 7, q = bidx >> 3;
+    const int stage = q % cp.stages;
+    const int chainIdx = (q / cp.stages) * 8 + xcd;
+    if (chainIdx >= cp.chains) return;
+    const int tile = cp.tile0 + chainIdx;
+    if (stage == cp.stages - 1) chain_head<F16, R, S, A, DUMP>(p, cp, lds, tile, chainIdx);
+    else chain_layers<F16, R, S, A, DUMP>(p, cp, lds, tile, chainIdx, stage);
+}
+
+}  // namespace wn

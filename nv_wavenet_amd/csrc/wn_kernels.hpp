@@ -466,6 +466,60 @@ WN_DEV void gemm_res(const typename Prec<F16>::frag (&wres)[NFR], int pos0, floa
 }
 
 // ------------------------------------------------------------------------------------------
+// softmax + inverse-CDF pick of ONE utterance by a group of LPU consecutive lanes (softmax.cuh:36-191;
+// oracle matrix.cpp:166-183 + nv_wavenet_reference.cpp:106-121).  Lane `sq` of the group holds the RPL
+// consecutive logits at `lrow` (row sq*RPL .. sq*RPL+RPL-1 of the A logits).  Returns, in every lane of
+// the group, the first row whose cumulative un-normalised probability exceeds sel * total (the oracle's
+// "sel < cumulative p"), or 128 when the scan falls off the end (softmax.cuh:154-155).  e[] receives
+// this lane's exp(logit - max) values and `total` their sum over the group (for the probability dump).
+// ------------------------------------------------------------------------------------------
+template <int A, int LPU, int RPL>
+WN_DEV int softmax_pick(const float* lrow, int sq, int lane, float sel, float (&e)[RPL], float& total) {
+#pragma unroll
+    for (int i = 0; i < RPL / 4; i++) {
+        floatx4 v = *(const floatx4*)(lrow + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; r++) e[i * 4 + r] = v[r];
+    }
+    float m = e[0];
+#pragma unroll
+    for (int i = 1; i < RPL; i++) m = __builtin_fmaxf(m, e[i]);
+#pragma unroll
+    for (int o = 1; o < LPU; o <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPL; i++) {
+        e[i] = fast_exp(e[i] - m);
+        lsum += e[i];
+    }
+    // inclusive scan of the lane sums over the LPU lanes of this utterance
+    float incl = lsum;
+#pragma unroll
+    for (int o = 1; o < LPU; o <<= 1) {
+        float up = __shfl_up(incl, o);
+        if (sq >= o) incl += up;
+    }
+    total = __shfl(incl, (lane & ~(LPU - 1)) + LPU - 1);
+    const float target = sel * total;
+    // first row of this lane whose cumulative sum exceeds the target
+    float cum = incl - lsum;   // exclusive prefix of this lane
+    int first = RPL;
+#pragma unroll
+    for (int i = 0; i < RPL; i++) {
+        cum += e[i];
+        first = (first == RPL && target < cum) ? i : first;
+    }
+    int pick = first < RPL ? sq * RPL + first : 0x7fffffff;
+#pragma unroll
+    for (int o = 1; o < LPU; o <<= 1) {
+        int other = __shfl_xor(pick, o);
+        pick = other < pick ? other : pick;
+    }
+    if (pick >= A) pick = 128;             // scan fell off the end (softmax.cuh:154-155)
+    return pick;
+}
+
+// ------------------------------------------------------------------------------------------
 // the engine kernel: one workgroup generates `count` samples for BT tiles of 16 utterances
 // ------------------------------------------------------------------------------------------
 // EMBLDS: both embedding tables are copied to LDS at launch, so the gather that follows every
@@ -986,54 +1040,13 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         wg_barrier();
         WN_TMARK(9)
 
-        // ---- softmax + inverse-CDF pick (softmax.cuh:36-191; oracle matrix.cpp:166-183,
-        //      nv_wavenet_reference.cpp:106-121): LPU lanes per utterance, RPL rows per lane ----
+        // ---- softmax + inverse-CDF pick: LPU lanes per utterance, RPL rows per lane (softmax_pick) ----
 #pragma unroll
         for (int bt = 0; bt < BT; bt++) {
             float e[C::RPL];
+            float total;
             const float* lrow = lgbuf + (bt * 16 + su) * C::LROW + sq * C::RPL;
-#pragma unroll
-            for (int i = 0; i < C::RPL / 4; i++) {
-                floatx4 v = *(const floatx4*)(lrow + i * 4);
-#pragma unroll
-                for (int r = 0; r < 4; r++) e[i * 4 + r] = v[r];
-            }
-            float m = e[0];
-#pragma unroll
-            for (int i = 1; i < C::RPL; i++) m = __builtin_fmaxf(m, e[i]);
-#pragma unroll
-            for (int o = 1; o < C::LPU; o <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
-            float lsum = 0.f;
-#pragma unroll
-            for (int i = 0; i < C::RPL; i++) {
-                e[i] = fast_exp(e[i] - m);
-                lsum += e[i];
-            }
-            // inclusive scan of the lane sums over the LPU lanes of this utterance
-            float incl = lsum;
-#pragma unroll
-            for (int o = 1; o < C::LPU; o <<= 1) {
-                float up = __shfl_up(incl, o);
-                if (sq >= o) incl += up;
-            }
-            const float total = __shfl(incl, (lane & ~(C::LPU - 1)) + C::LPU - 1);
-            const float target = selv[bt] * total;
-            // first row of this lane whose cumulative sum exceeds the target
-            // (the oracle picks the first row with sel < cumsum)
-            float cum = incl - lsum;   // exclusive prefix of this lane
-            int first = C::RPL;
-#pragma unroll
-            for (int i = 0; i < C::RPL; i++) {
-                cum += e[i];
-                first = (first == C::RPL && target < cum) ? i : first;
-            }
-            int pick = first < C::RPL ? sq * C::RPL + first : 0x7fffffff;
-#pragma unroll
-            for (int o = 1; o < C::LPU; o <<= 1) {
-                int other = __shfl_xor(pick, o);
-                pick = other < pick ? other : pick;
-            }
-            if (pick >= A) pick = 128;             // scan fell off the end (softmax.cuh:154-155)
+            const int pick = softmax_pick<A, C::LPU, C::RPL>(lrow, sq, lane, selv[bt], e, total);
             const int sb = (tile0 + bt) * 16 + su;
             if (sq == 0) {
                 ybuf[bt * 16 + su] = pick;
@@ -1090,34 +1103,63 @@ static __global__ void mulaw_pcm_kernel(const int* __restrict__ yOut, short* __r
 
 // fp32 col-major M x K -> per-wave fragment streams.  Wave w gets the tiles t = w + NW*i in
 // order (gateRT=0), or for the gated 2R x R matrices the pairs (t, t+RT) (gateRT=RT>0).
-// dst + w*waveStride is the start of this matrix inside wave w's stream.
+// dst + w*waveStride is the start of this matrix inside wave w's stream; idx = element of the packed matrix.
 template <bool F16>
-__global__ void pack_weight_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src, int M,
-                                   int K, int NW, size_t waveStride, int gateRT) {
+WN_DEV void pack_weight_elem(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src, int M, int K,
+                             int NW, size_t waveStride, int gateRT, size_t idx) {
     constexpr int EPL = Prec<F16>::EPL, TPF = Prec<F16>::TPF;
     const int KF = K / (16 * TPF);
     const int tilesPerWave = M / 16 / NW;
     const size_t perWave = (size_t)tilesPerWave * KF * 64 * EPL;
+    const int w = idx / perWave;
+    size_t r = idx % perWave;
+    const int e = r % EPL; r /= EPL;
+    const int lane = r % 64; r /= 64;
+    // slot order inside a matrix: groups of G slots, k-fragment-major inside a group (see gemm())
+    const int G = tilesPerWave >= 4 ? 4 : tilesPerWave;
+    const int mi = r % G;
+    const int kf = (r / G) % KF;
+    const int it = (r / (G * KF)) * G + mi;        // tile slot inside the wave's list
+    int tile;
+    if (gateRT > 0) tile = w + NW * (it >> 1) + (it & 1) * gateRT;
+    else tile = w + NW * it;
+    const int i = lane & 15, g = lane >> 4;
+    const int m = tile * 16 + i;
+    const int k = (kf * TPF + (e >> 2)) * 16 + g * 4 + (e & 3);
+    float v = src[(size_t)m + (size_t)k * M];
+    if (gateRT > 0) v *= gate_prescale<F16>(m >= M / 2);    // gated 2R x R matrix: see gate1()
+    dst[(size_t)w * waveStride + (idx % perWave)] = (typename Prec<F16>::elem)v;
+}
+template <bool F16>
+__global__ void pack_weight_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src, int M,
+                                   int K, int NW, size_t waveStride, int gateRT) {
     const size_t n = (size_t)M * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)
+        pack_weight_elem<F16>(dst, src, M, K, NW, waveStride, gateRT, idx);
+}
+
+// One layer in one launch (setLayerWeights): the four matrices into the per-wave streams and the three
+// bias vectors into the fp32 table (gate biases pre-scaled like the gate matrices).
+struct LayerSrc {
+    const float *Wprev, *Wcur, *Bh, *Wres, *Bres, *Wskip, *Bskip;
+};
+template <bool F16>
+__global__ void pack_layer_kernel(typename Prec<F16>::elem* __restrict__ layerFrags, float* __restrict__ biasL, LayerSrc s,
+                                  int R, int S, int NW, size_t waveStride, int oPrev, int oCur, int oRes, int oSkip) {
+    constexpr int FE = 64 * Prec<F16>::EPL;
+    const size_t nGate = (size_t)2 * R * R, nRes = (size_t)R * R, nSkip = (size_t)S * R;
+    const size_t nW = 2 * nGate + nRes + nSkip, n = nW + 3 * R + S;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const int w = idx / perWave;
-        size_t r = idx % perWave;
-        const int e = r % EPL; r /= EPL;
-        const int lane = r % 64; r /= 64;
-        // slot order inside a matrix: groups of G slots, k-fragment-major inside a group (see gemm())
-        const int G = tilesPerWave >= 4 ? 4 : tilesPerWave;
-        const int mi = r % G;
-        const int kf = (r / G) % KF;
-        const int it = (r / (G * KF)) * G + mi;        // tile slot inside the wave's list
-        int tile;
-        if (gateRT > 0) tile = w + NW * (it >> 1) + (it & 1) * gateRT;
-        else tile = w + NW * it;
-        const int i = lane & 15, g = lane >> 4;
-        const int m = tile * 16 + i;
-        const int k = (kf * TPF + (e >> 2)) * 16 + g * 4 + (e & 3);
-        float v = src[(size_t)m + (size_t)k * M];
-        if (gateRT > 0) v *= gate_prescale<F16>(m >= M / 2);    // gated 2R x R matrix: see gate1()
-        dst[(size_t)w * waveStride + (idx % perWave)] = (typename Prec<F16>::elem)v;
+        if (idx < nGate) pack_weight_elem<F16>(layerFrags + (size_t)oPrev * FE, s.Wprev, 2 * R, R, NW, waveStride, R / 16, idx);
+        else if (idx < 2 * nGate) pack_weight_elem<F16>(layerFrags + (size_t)oCur * FE, s.Wcur, 2 * R, R, NW, waveStride, R / 16, idx - nGate);
+        else if (idx < 2 * nGate + nRes) pack_weight_elem<F16>(layerFrags + (size_t)oRes * FE, s.Wres, R, R, NW, waveStride, 0, idx - 2 * nGate);
+        else if (idx < nW) pack_weight_elem<F16>(layerFrags + (size_t)oSkip * FE, s.Wskip, S, R, NW, waveStride, 0, idx - 2 * nGate - nRes);
+        else {
+            const int i = (int)(idx - nW);
+            if (i < 2 * R) biasL[i] = s.Bh[i] * gate_prescale<F16>(i >= R);
+            else if (i < 3 * R) biasL[i] = s.Bres[i - 2 * R];
+            else biasL[i] = s.Bskip[i - 3 * R];
+        }
     }
 }
 
@@ -1128,32 +1170,61 @@ __global__ void convert_kernel(typename Prec<F16>::elem* __restrict__ dst, const
         dst[i] = (typename Prec<F16>::elem)src[i];
 }
 
-// conditioning: fp32 [rows = samples*L][maxBatch][2R] -> [rows][tiles][wave][COND_FR][lane][EPL]
-// fragment c, element e of wave w: gate slot it = c*TPF + (e>>2) -> tile = w + NW*(it>>1) + (it&1)*RT
-template <bool F16>
-__global__ void pack_cond_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src,
-                                 size_t rows, int maxBatch, int tiles, int R, int NW) {
+// conditioning: fp32 [rows = samples*L][maxBatch][2R] -> T_data fragments, gate rows pre-scaled.
+//   STREAM = false (wavenet_wg / wavenet_chain): [rows][tiles][wave][COND_FR][lane][EPL];
+//       fragment c, element e of wave w: gate slot it = c*TPF + (e>>2) -> tile = w + NW*(it>>1) + (it&1)*RT
+//   STREAM = true (wavenet_stream): [rows][tiles][2R/(16*TPF)][lane][EPL], tiles in natural order
+// One workgroup per (row, tile of 16 utterances): the 16 x 2R fp32 source block is contiguous (8 KB at
+// R = 64) and is read with coalesced 16-byte loads into LDS; the 2R*16 destination elements are
+// contiguous too and are written as one 16-byte piece per thread.  (The first version gathered one
+// scalar per thread straight from global memory: 2.2-4.5x read amplification, 19 ms for 256 samples x
+// 8192 utterances; this one moves source + destination bytes once.)
+template <bool F16, int R, bool STREAM>
+__global__ __launch_bounds__(256) void pack_cond_tiled_kernel(typename Prec<F16>::elem* __restrict__ dst,
+                                                              const float* __restrict__ src, size_t rows, int maxBatch,
+                                                              int tiles) {
+    using elem = typename Prec<F16>::elem;
+    using frag = typename Prec<F16>::frag;
     constexpr int EPL = Prec<F16>::EPL, TPF = Prec<F16>::TPF;
-    const int RT = R / 16;
-    const int CF = 2 * (RT / NW) / TPF;
-    const size_t perRow = (size_t)tiles * NW * CF * 64 * EPL;
-    const size_t n = rows * perRow;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = idx / perRow;
-        size_t r = idx % perRow;
-        const int e = r % EPL; r /= EPL;
-        const int lane = r % 64; r /= 64;
-        const int c = r % CF; r /= CF;
-        const int w = r % NW;
-        const int tl = r / NW;
-        const int j = lane & 15, g = lane >> 4;
-        const int b = tl * 16 + j;
-        const int it = c * TPF + (e >> 2);
-        const int tile = w + NW * (it >> 1) + (it & 1) * RT;
-        const int ch = tile * 16 + g * 4 + (e & 3);
-        float v = 0.f;
-        if (b < maxBatch) v = src[(row * maxBatch + b) * 2 * R + ch] * gate_prescale<F16>(ch >= R);
-        dst[idx] = (typename Prec<F16>::elem)v;
+    constexpr int R2 = 2 * R, RT = R / 16, NW = RT >= 4 ? 4 : RT;
+    constexpr int COND_FR = 2 * (RT / NW) / TPF;
+    constexpr int LROWF = R2 + 4;                  // padded LDS row (floats)
+    __shared__ __attribute__((aligned(16))) float blk[16 * LROWF];
+    const size_t nblk = rows * (size_t)tiles;
+    for (size_t bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const size_t row = bi / tiles;
+        const int b0 = (int)(bi % tiles) * 16;
+        const float* s = src + (row * maxBatch + b0) * R2;
+        for (int i = threadIdx.x; i < 16 * R2 / 4; i += 256) {
+            const int jj = i / (R2 / 4), c4 = i % (R2 / 4);
+            floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (b0 + jj < maxBatch) v = __builtin_nontemporal_load((const floatx4*)(s + (size_t)jj * R2 + c4 * 4));
+            *(floatx4*)(blk + jj * LROWF + c4 * 4) = v;
+        }
+        __syncthreads();
+        elem* d = dst + bi * (size_t)(16 * R2);
+        for (int pi = threadIdx.x; pi < 16 * R2 / EPL; pi += 256) {
+            const int lane = pi & 63, fr = pi >> 6;
+            const int j = lane & 15, g = lane >> 4;
+            frag o;
+#pragma unroll
+            for (int q = 0; q < EPL / 4; q++) {
+                int tile16;
+                if (STREAM) tile16 = fr * TPF + q;
+                else {
+                    const int w = fr / COND_FR, c = fr % COND_FR;
+                    const int it = c * TPF + q;
+                    tile16 = w + NW * (it >> 1) + (it & 1) * RT;
+                }
+                const int ch = tile16 * 16 + g * 4;
+                const floatx4 v = *(const floatx4*)(blk + j * LROWF + ch);
+                const float sc = gate_prescale<F16>(ch >= R);
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[q * 4 + r] = (elem)(v[r] * sc);
+            }
+            __builtin_nontemporal_store(o, (frag*)(d + (size_t)pi * EPL));
+        }
+        __syncthreads();
     }
 }
 

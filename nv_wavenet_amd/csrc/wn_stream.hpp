@@ -543,28 +543,4 @@ __global__ void pack_weight_stream_kernel(typename Prec<F16>::elem* __restrict__
     }
 }
 
-// conditioning: fp32 [rows = samples*L][maxBatch][2R] -> [rows][tiles][fragment][lane][EPL]
-template <bool F16>
-__global__ void pack_cond_stream_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src,
-                                        size_t rows, int maxBatch, int tiles, int R2) {
-    constexpr int EPL = Prec<F16>::EPL, TPF = Prec<F16>::TPF;
-    const int CF = R2 / (16 * TPF);
-    const size_t perRow = (size_t)tiles * CF * 64 * EPL;
-    const size_t n = rows * perRow;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = idx / perRow;
-        size_t r = idx % perRow;
-        const int e = r % EPL; r /= EPL;
-        const int lane = r % 64; r /= 64;
-        const int c = r % CF;
-        const int tl = r / CF;
-        const int j = lane & 15, g = lane >> 4;
-        const int b = tl * 16 + j;
-        const int ch = (c * TPF + (e >> 2)) * 16 + g * 4 + (e & 3);
-        float v = 0.f;
-        if (b < maxBatch) v = src[(row * maxBatch + b) * R2 + ch] * gate_prescale<F16>(ch >= R2 / 2);
-        dst[idx] = (typename Prec<F16>::elem)v;
-    }
-}
-
 }  // namespace wn

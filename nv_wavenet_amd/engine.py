@@ -21,6 +21,18 @@ class Impl:
     MANYBLOCK = 4
 
 
+class Org:
+    """Kernel organisations (nvwOrganisation in nv_wavenet.hpp; last argument of nvw_create_ex)."""
+    AUTO = 0        # from the Implementation value and the batch size
+    WG = 1          # wn::wavenet_wg, 1 or 2 tiles of 16 utterances per workgroup by batch size
+    WG1 = 2
+    WG2 = 3
+    STREAM = 4      # wn::wavenet_stream (loader / consumer waves)
+    CHAIN = 5       # wn::wavenet_chain: multi-CU, weights resident, fewest CUs
+    CHAIN1 = 6      # wn::wavenet_chain, one layer per CU
+    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "stream": 4, "chain": 5, "chain1": 6}
+
+
 def supported_configs():
     buf = (C.c_int * 256)()
     n = lib.nvw_list_supported(buf, 64)
@@ -38,7 +50,7 @@ def _f32(x):
 
 class WavenetEngine:
     def __init__(self, R, S, A, numLayers, maxDilation, batchSize, numSamples, impl=0, tanhEmbed=True,
-                 precision=32):
+                 precision=32, organisation=0):
         if not lib.nvw_supported(R, S, A, precision):
             raise ValueError("no nvWavenetInfer<%s,R=%d,S=%d,A=%d> in this build; have %s" %
                              ("half2,half" if precision == 16 else "float,float", R, S, A, supported_configs()))
@@ -48,10 +60,14 @@ class WavenetEngine:
         self.numLayers, self.maxDilation = numLayers, maxDilation
         self.maxBatch, self.maxSamples = batchSize, numSamples
         self.precision = precision
-        self._h = lib.nvw_create(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
-                                 1 if tanhEmbed else 0)
+        if isinstance(organisation, str) or organisation is None:
+            organisation = Org.BY_NAME[organisation]
+        if organisation not in range(7):
+            raise ValueError("organisation must be 0..6")
+        self._h = lib.nvw_create_ex(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
+                                    1 if tanhEmbed else 0, organisation)
         if not self._h:
-            raise RuntimeError("nvw_create failed")
+            raise RuntimeError("nvw_create failed: shape not supported in this organisation")
         self._cb_keep = None
 
     def close(self):
@@ -78,21 +94,38 @@ class WavenetEngine:
         a = [_f32(x) for x in (Wzs, Bzs, Wza, Bza)]
         lib.nvw_set_out_weights(self._h, *[addr(x) for x in a])
 
-    def setInputs(self, Lh, outputSelectors):
-        """Lh [maxSamples][L][maxBatch][2R] fp32, outputSelectors [maxSamples][maxBatch] fp32."""
+    def setInputs(self, Lh, outputSelectors, numSamples=None):
+        """Lh [numSamples][L][maxBatch][2R] fp32, outputSelectors [numSamples][maxBatch] fp32;
+        numSamples defaults to the engine's capacity (the reference's setInputs), may be smaller."""
         Lh, sel = _f32(Lh), _f32(outputSelectors)
-        n = self.maxSamples * self.numLayers * self.maxBatch * 2 * self.R
+        ns = self.maxSamples if numSamples is None else int(numSamples)
+        assert 0 < ns <= self.maxSamples
+        n = ns * self.numLayers * self.maxBatch * 2 * self.R
         assert (Lh.numel() if hasattr(Lh, "numel") else Lh.size) == n, "Lh has the wrong size"
-        assert (sel.numel() if hasattr(sel, "numel") else sel.size) == self.maxSamples * self.maxBatch
-        lib.nvw_set_inputs(self._h, addr(Lh), addr(sel))
+        assert (sel.numel() if hasattr(sel, "numel") else sel.size) == ns * self.maxBatch
+        lib.nvw_set_inputs_n(self._h, addr(Lh), addr(sel), ns)
 
     # ---- beyond the reference class (include/nv_wavenet_c.h, "extensions") ---------------------
-    def setConditioning(self, Lh):
+    def setConditioning(self, Lh, numSamples=None):
         """The conditioning half of setInputs; pair with setSelectorSeed (no selector matrix)."""
         Lh = _f32(Lh)
-        n = self.maxSamples * self.numLayers * self.maxBatch * 2 * self.R
+        ns = self.maxSamples if numSamples is None else int(numSamples)
+        assert 0 < ns <= self.maxSamples
+        n = ns * self.numLayers * self.maxBatch * 2 * self.R
         assert (Lh.numel() if hasattr(Lh, "numel") else Lh.size) == n, "Lh has the wrong size"
-        lib.nvw_set_conditioning(self._h, addr(Lh))
+        lib.nvw_set_conditioning_n(self._h, addr(Lh), ns)
+
+    def packConditioning(self, Lh, firstSample, count, stream=None):
+        """Conditioning streamed chunk by chunk: Lh [count][L][maxBatch][2R] fp32 ON THE DEVICE holds samples
+        firstSample .. firstSample+count-1; packed asynchronously on `stream` (history untouched)."""
+        Lh = _f32(Lh)
+        assert hasattr(Lh, "data_ptr") and Lh.is_cuda, "packConditioning takes device tensors"
+        assert Lh.numel() == count * self.numLayers * self.maxBatch * 2 * self.R
+        lib.nvw_pack_conditioning(self._h, addr(Lh), int(firstSample), int(count), stream)
+
+    def chainStatus(self):
+        """0 when every multi-CU launch ran to completion (synchronises), else the first time-out code."""
+        return int(lib.nvw_chain_status(self._h))
 
     def kernelInfo(self, batch_size=None, dumpActivations=False):
         """The device code run(n, batch_size, ..., dumpActivations) launches (kernel + template arguments)."""
@@ -121,7 +154,7 @@ class WavenetEngine:
         lib.nvw_set_audio_out(self._h, addr(pcmOut) if pcmOut is not None else None)
 
     # ---- run --------------------------------------------------------------------------------
-    def _yout(self, yOut):
+    def _yout(self, yOut, need=None):
         if yOut is None:
             return None
         if hasattr(yOut, "data_ptr"):
@@ -130,17 +163,17 @@ class WavenetEngine:
         else:
             assert yOut.dtype == np.int32 and yOut.flags["C_CONTIGUOUS"]
         n = yOut.numel() if hasattr(yOut, "numel") else yOut.size
-        assert n >= self.maxBatch * self.maxSamples, "yOut must hold [maxBatch][maxSamples] int32"
+        assert n >= self.maxBatch * (self.maxSamples if need is None else need), "yOut must hold [maxBatch][num_samples] int32"
         return addr(yOut)
 
     def run(self, num_samples, batch_size, yOut=None, batch_size_per_block=1, dumpActivations=False, stream=None):
-        ok = lib.nvw_run(self._h, num_samples, batch_size, self._yout(yOut), batch_size_per_block,
+        ok = lib.nvw_run(self._h, num_samples, batch_size, self._yout(yOut, num_samples), batch_size_per_block,
                          1 if dumpActivations else 0, stream)
         return bool(ok)
 
     def run_partial(self, init_sample, num_samples, batch_size, yOut=None, batch_size_per_block=1,
                     dumpActivations=False, stream=None):
-        ok = lib.nvw_run_partial(self._h, init_sample, num_samples, batch_size, self._yout(yOut),
+        ok = lib.nvw_run_partial(self._h, init_sample, num_samples, batch_size, self._yout(yOut, num_samples),
                                  batch_size_per_block, 1 if dumpActivations else 0, stream)
         return bool(ok)
 
@@ -153,7 +186,7 @@ class WavenetEngine:
         cb = CONSUME_FN(_cb)
         self._cb_keep = cb
         ok = lib.nvw_run_chunks(self._h, num_samples_per_chunk, cb, None, num_samples, batch_size,
-                                self._yout(yOut), batch_size_per_block, 1 if dumpActivations else 0, stream)
+                                self._yout(yOut, num_samples), batch_size_per_block, 1 if dumpActivations else 0, stream)
         return bool(ok)
 
     # ---- getters (host numpy, reference layouts) ----------------------------------------------

@@ -7,6 +7,8 @@ including the per-chunk copies of the samples to the host).
   -l layers  -r R  -s S  -a A  -b batch  -c batch_size_per_block  -n samples  -d max_dilation
   -m mode (0 AUTO 1 SINGLE 2 DUAL 3 PERSISTENT 4 MANYBLOCK)  -p precision (16|32)
   -t samples_per_chunk  -f device
+Extension: -o organisation (0 = from -m and the batch size, 1..6 see include/nv_wavenet_c.h: nvw_create_ex);
+the line "kernel: ..." reports the device code that ran.
 """
 import argparse
 import os
@@ -22,7 +24,8 @@ def main():
     for flag, name, default in (("-l", "num_layers", 20), ("-r", "r", 64), ("-s", "s", 128), ("-a", "a", 256),
                                 ("-b", "batch_size", 1), ("-c", "batch_size_per_block", 1),
                                 ("-n", "num_samples", 16384), ("-d", "max_dilation", 512), ("-m", "mode", 0),
-                                ("-p", "precision", 16), ("-t", "num_samples_per_chunk", 2048), ("-f", "device", 0)):
+                                ("-p", "precision", 16), ("-t", "num_samples_per_chunk", 2048), ("-f", "device", 0),
+                                ("-o", "organisation", 0)):
         ap.add_argument(flag, dest=name, type=int, default=default)
     o = ap.parse_args()
     import torch
@@ -35,7 +38,8 @@ def main():
     rng = np.random.default_rng(1)   # the reference seeds srand(1)
     R, S, A, L, B, N = o.r, o.s, o.a, o.num_layers, o.batch_size, o.num_samples
     u = lambda sc, *shape: ((rng.random(shape, dtype=np.float32) - 0.5) * sc).astype(np.float32)
-    e = WavenetEngine(R, S, A, L, o.max_dilation, B, N, impl=o.mode, precision=o.precision)
+    e = WavenetEngine(R, S, A, L, o.max_dilation, B, N, impl=o.mode, precision=o.precision, organisation=o.organisation)
+    print("kernel: %s" % e.kernelInfo(B, False))
     # the reference uploads uniform [-0.5,0.5] weights and leaves embeddings / conditioning
     # uninitialised (nv_wavenet_perf.cu:40-63); here the parity recipe's scales keep values finite
     e.setEmbeddings(u(0.5 / R, A, R), u(0.5 / R, A, R))
@@ -47,15 +51,19 @@ def main():
     Lh = torch.empty(N, L, B, 2 * R, dtype=torch.float32, device="cuda").uniform_(-0.25 / R, 0.25 / R, generator=g)
     sel = torch.rand(N, B, dtype=torch.float32, device="cuda", generator=g)
     e.setInputs(Lh, sel)
-    del Lh
     y = torch.zeros(B, N, dtype=torch.int32).pin_memory()
     e.run(min(N, 64), B)            # warm-up (code objects, clocks)
     e.synchronize()
+    e.setInputs(Lh, sel)            # history back to silence, like a fresh utterance
+    del Lh
     t0 = time.perf_counter()
     ok = e.run_chunks(o.num_samples_per_chunk, None, N, B, y.numpy(), o.batch_size_per_block)
     e.synchronize()
     ms = 1e3 * (time.perf_counter() - t0)
-    print("Sample rate: %f kHz" % (N / ms if ok else 0.0))
+    st = e.chainStatus()
+    if st:
+        print("multi-CU hand-off timed out: code 0x%x" % st)
+    print("Sample rate: %f kHz" % (N / ms if ok and not st else 0.0))
 
 
 if __name__ == "__main__":

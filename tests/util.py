@@ -6,6 +6,8 @@ import numpy as np
 from oracle import oracle as O
 import cases
 
+# test "mode" names -> nvwOrganisation (wg = exactly one tile per workgroup, the latency kernel as first built)
+MODE_ORG = {None: 0, "auto": 0, "wg": 2, "wg2": 3, "stream": 4, "chain": 5, "chain1": 6}
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -32,27 +34,16 @@ def make_oracle(case, t):
 
 def make_engine(case, t, precision=32, impl=None, device_ptrs=False, mode=None):
     """Build the HIP engine through the C ABI and upload the model + inputs.
-    mode: None = the engine's own choice by batch size; "wg" / "wg2" / "stream" force a kernel
-    organisation (NVW_MODE is read by the engine at construction)."""
+    mode: None = the engine's own choice from the Implementation value and the batch size; "wg" / "wg2" /
+    "stream" / "chain" / "chain1" force a kernel organisation (nvw_create_ex)."""
     from nv_wavenet_amd import WavenetEngine
-    s = case.shape
-    old = os.environ.get("NVW_MODE")
-    if mode is not None:
-        os.environ["NVW_MODE"] = mode
-    try:
-        return _make_engine(WavenetEngine, case, t, precision, impl, device_ptrs)
-    finally:
-        if mode is not None:
-            if old is None:
-                os.environ.pop("NVW_MODE", None)
-            else:
-                os.environ["NVW_MODE"] = old
+    return _make_engine(WavenetEngine, case, t, precision, impl, device_ptrs, mode)
 
 
-def _make_engine(WavenetEngine, case, t, precision, impl, device_ptrs):
+def _make_engine(WavenetEngine, case, t, precision, impl, device_ptrs, mode=None):
     s = case.shape
     e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, s.B, s.N, impl=case.impl if impl is None else impl,
-                      tanhEmbed=True, precision=precision)
+                      tanhEmbed=True, precision=precision, organisation=MODE_ORG[mode])
     conv = (lambda a: a)
     if device_ptrs:
         import torch
