@@ -49,7 +49,7 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
 struct ChainParams {
-    unsigned long long* mail;   // [chain][stage][x granules | skip granules], zeroed before every launch
+    unsigned long long* mail;   // [chain][stage] placement words (padded to 64), then [chain][stage][x granules | skip granules]; zeroed before every launch
     unsigned* status;           // [0]: 0 = fine, else the code of the first time-out (host checks after the launch)
     int stages;                 // layer stages + 1 (head)
     int lpc;                    // layers per layer stage (<= CCfg::LPC)
@@ -64,33 +64,72 @@ struct CCfg {
     using C = Cfg<F16, R, S, A, 1>;
     static constexpr int NW = C::NW, FLW = C::FLW, FHW = C::FHW;
     static constexpr int LDS_MAX = 160 * 1024;
-    static constexpr int REG_FRAGS = 80;                   // weight fragments a wave keeps in registers (320 of 512)
     static constexpr int MAX_LPC = 8;
-    // ---- layer stage with n layers: x image | n h images | n x (biases + running skip bias) | weights ----
-    static constexpr int fixedLds(int n) { return C::XBUF + n * C::HBUF + n * (C::BIAS_L + S) * 4; }
-    static constexpr int ldsFrags(int n) {                // fragments per layer per wave that live in LDS
+    // ---- layer stage with n layers.  Where a weight fragment lives decides what it costs to use:
+    //   * accumulator registers (AGPRs): free -- an MFMA reads its A operand straight from them -- IF the value
+    //     is pinned there (agpr_pin below).  Left to place 300 registers of weights itself, the compiler keeps
+    //     them in the VGPR class, spills them to AGPRs and copies every fragment back in front of its MFMA
+    //     (4 v_accvgpr_read + wait states: the cur GEMM of a C4 layer took 0.315 us for 20 MFMAs, 0.19 pinned);
+    //   * architectural VGPRs: free, but the file (256) also holds the whole working set;
+    //   * LDS: one ds_read_b128 per use; at 1 KiB per MFMA and wave the four SIMDs together would need all of
+    //     the LDS bandwidth (256 B/clk), so LDS is for the GEMMs that run while the stage waits.
+    // So the weights of the arrival-to-departure path (class A: Wcur, Wres) take the AGPRs first, then VGPRs,
+    // then LDS; the weights used while the stage waits (class B: Wprev, Wskip) take what AGPRs are left,
+    // then LDS, then VGPRs.
+    static constexpr int FA = C::FW_GATE + C::FW_RES;      // class A fragments per layer per wave (cur | res)
+    static constexpr int FB = C::FW_GATE + C::FW_SKIP;     // class B (prev | skip)
+#ifndef WN_CHAIN_AGPR_FRAGS
+#define WN_CHAIN_AGPR_FRAGS 64                             // fp16: the whole accumulator file (the accumulators live in VGPRs:
+#endif                                                     // -amdgpu-mfma-vgpr-form); fp32 builds keep theirs in AGPRs
+#ifndef WN_CHAIN_VGPR_FRAGS
+#define WN_CHAIN_VGPR_FRAGS 16                             // weight fragments a wave may keep in VGPRs (64 registers)
+#endif
+    // (fp32 = the parity mode: its accumulators need part of the AGPR file, and it may keep more weights in the
+    //  VGPR class than fit beside the working set -- the compiler then spills, which only costs time)
+    static constexpr int AGPR_FRAGS = F16 ? WN_CHAIN_AGPR_FRAGS : 44, VGPR_FRAGS = F16 ? WN_CHAIN_VGPR_FRAGS : 36;
+    // LDS: x image | n h images | n x (Bh, Bres) | weights
+    static constexpr int fixedLds(int n) { return C::XBUF + n * C::HBUF + n * 3 * R * 4; }
+    static constexpr int ldsAvail(int n) {                // weight fragments per layer per wave that fit in LDS
         int avail = (LDS_MAX - fixedLds(n)) / (n * NW * 1024);
-        return avail < 0 ? 0 : (avail > FLW ? FLW : avail);
+        return avail < 0 ? 0 : avail;
     }
-    static constexpr bool fits(int n) { return LDS_MAX > fixedLds(n) && (FLW - ldsFrags(n)) * n <= REG_FRAGS; }
+    struct Split {
+        int aa, va, la;   // class A: AGPR / VGPR / LDS
+        int ab, lb, vb;   // class B: AGPR / LDS / VGPR
+        bool ok;
+    };
+    static constexpr Split split(int n) {
+        Split s{};
+        const int per = AGPR_FRAGS / n, avail = ldsAvail(n), vper = VGPR_FRAGS / n;
+        s.aa = cmin(FA, per);
+        s.ab = cmin(FB, per - s.aa);
+        s.va = cmin(FA - s.aa, vper);
+        s.la = FA - s.aa - s.va;
+        s.lb = cmin(FB - s.ab, avail - s.la > 0 ? avail - s.la : 0);
+        s.vb = FB - s.ab - s.lb;
+        s.ok = LDS_MAX > fixedLds(n) && s.la <= avail && s.va + s.vb <= vper;
+        return s;
+    }
     static constexpr int pickLpc() {
         int best = 0;
         for (int n = 1; n <= MAX_LPC; n++)
-            if (fits(n)) best = n;
+            if (split(n).ok) best = n;
         return best;
     }
     static constexpr int LPC = pickLpc();                  // 0: not even one layer fits a CU (no chain for this shape)
     static constexpr bool SUPPORTED = LPC > 0;
     static constexpr int LP = LPC > 0 ? LPC : 1;
-    static constexpr int NLD = ldsFrags(LP);               // fragments per layer per wave in LDS (the tail of the layer stream)
-    static constexpr int NRG = FLW - NLD;                  // ... in registers (the head of the layer stream)
+    static constexpr Split SP = split(LP);
+    static constexpr int NAA = SP.aa, NVA = SP.va, NLA = SP.la;    // class A positions [0,NAA) AGPR, then VGPR, then LDS
+    static constexpr int NAB = SP.ab, NLB = SP.lb, NVB = SP.vb;    // class B positions [0,NAB) AGPR, then LDS, then VGPR
+    static constexpr int NAG = NAA + NAB, NVG = NVA + NVB, NLD = NLA + NLB;   // per layer per wave: AGPR [A|B], VGPR [A|B], LDS [A|B]
     static constexpr int OFF_LX = 0, OFF_LH = C::XBUF, OFF_LB = OFF_LH + LP * C::HBUF;
-    static constexpr int OFF_LW = (OFF_LB + LP * (C::BIAS_L + S) * 4 + 15) & ~15;
+    static constexpr int OFF_LW = (OFF_LB + LP * 3 * R * 4 + 15) & ~15;
     static constexpr int LAYER_LDS = OFF_LW + LP * NW * NLD * 1024;
     // ---- head stage: skip image | zs image | logits | picks | biases (final skip bias, Bzs, Bza) | embeddings ----
     // the head's weights stay in registers when they fit (64 fragments at C3 / C4), else they are streamed
     // through the prefetch ring like wavenet_wg does (large A, fp32)
-    static constexpr int HEADREGS = 288;
+    static constexpr int HEADREGS = F16 ? 256 : 144;
     static constexpr int HR = FHW * 4 <= HEADREGS ? FHW : (C::FW_ZA * 4 <= HEADREGS ? C::FW_ZA : 0);
     static constexpr int HS = FHW - HR;
     static constexpr int OFF_HSK = 0, OFF_HZS = C::SKBUF;
@@ -106,7 +145,8 @@ struct CCfg {
     }
     // mailboxes of one stage, in granules
     static constexpr int XG = R * 16, SG = S * 16;
-    static constexpr size_t mailGranules(int chains, int stages) { return (size_t)chains * stages * (XG + SG); }
+    static constexpr size_t placeWords(int chains, int stages) { return ((size_t)chains * stages + 63) & ~(size_t)63; }
+    static constexpr size_t mailGranules(int chains, int stages) { return placeWords(chains, stages) + (size_t)chains * stages * (XG + SG); }
 };
 
 // Experiment build (-DWN_CHAIN_TIMING): wave 0 of every stage stamps the 100 MHz wall clock (one counter for
@@ -145,7 +185,10 @@ WN_DEV bool spin_more(Spin& s, unsigned code) {
             return false;
         }
     }
-    __builtin_amdgcn_s_sleep(1);
+#ifndef WN_CHAIN_SLEEP
+#define WN_CHAIN_SLEEP 1
+#endif
+    if (WN_CHAIN_SLEEP > 0) __builtin_amdgcn_s_sleep(WN_CHAIN_SLEEP);
     return true;
 }
 
@@ -153,10 +196,14 @@ WN_DEV bool spin_more(Spin& s, unsigned code) {
 // coalesced access per wave instruction)
 WN_DEV int granule_at(int tile, int r, int lane) { return (tile * 4 + r) * 64 + lane; }
 
-// this wave's tiles w, w+NW, ... of a vector in MFMA D layout -> the consumer's mailbox
-template <int NT, int NW>
-WN_DEV void send_tiles(unsigned long long* mbox, int w, int lane, unsigned tag, const floatx4 (&v)[NT]) {
-    gu64* g = (gu64*)mbox;
+// this wave's tiles w, w+NW, ... of a vector in MFMA D layout -> the consumer's mailbox.
+// sameXcd: the consumer was found on this XCD (chain_place below).  Then the granules are stored at workgroup
+// scope: they go through this CU's write-through L1 into the L2 both CUs share and STAY there, so the
+// consumer's L1-bypassing sweep is served by L2; an agent-scope (sc1) store writes through to the fabric and
+// drops the line from L2, and every sweep pass of the consumer goes out to memory
+// (MI355X_MICROARCH.md, "stores of each flavour").  Across XCDs the agent-scope store is the only valid form.
+template <int NT, int NW, int SCOPE>
+WN_DEV void send_tiles_scope(gu64* g, int w, int lane, unsigned tag, const floatx4 (&v)[NT]) {
 #pragma unroll
     for (int i = 0; i < NT; i++)
 #pragma unroll
@@ -164,36 +211,121 @@ WN_DEV void send_tiles(unsigned long long* mbox, int w, int lane, unsigned tag, 
             // (through a scalar: __builtin_bit_cast applied to the vector-element lvalue v[i][r] itself reads element 0)
             const float f = v[i][r];
             __hip_atomic_store(g + granule_at(w + NW * i, r, lane), ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(f),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                               __ATOMIC_RELAXED, SCOPE);
         }
+}
+template <int NT, int NW>
+WN_DEV void send_tiles(unsigned long long* mbox, int w, int lane, unsigned tag, const floatx4 (&v)[NT], bool sameXcd) {
+    if (sameXcd) send_tiles_scope<NT, NW, __HIP_MEMORY_SCOPE_WORKGROUP>((gu64*)mbox, w, lane, tag, v);
+    else send_tiles_scope<NT, NW, __HIP_MEMORY_SCOPE_AGENT>((gu64*)mbox, w, lane, tag, v);
+}
+// one sweep pass: issue the loads of this wave's granules (agent scope: L1 is bypassed)
+template <int NT, int NW>
+WN_DEV void sweep_issue(const unsigned long long* mbox, int w, int lane, unsigned long long (&q)[NT * 4]) {
+    gu64* g = (gu64*)mbox;
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            q[i * 4 + r] = __hip_atomic_load(g + granule_at(w + NW * i, r, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ... and its check: true when every granule of the wave carries `tag` (then v holds the payload)
+template <int NT>
+WN_DEV bool sweep_check(const unsigned long long (&q)[NT * 4], unsigned tag, floatx4 (&v)[NT]) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v[i][r] = __uint_as_float((unsigned)q[i * 4 + r]);
+            ok &= (unsigned)(q[i * 4 + r] >> 32) == tag;
+        }
+    return __all(ok);
 }
 // the same tiles, swept until every granule carries `tag`
 template <int NT, int NW>
 WN_DEV bool recv_tiles(const unsigned long long* mbox, int w, int lane, unsigned tag, floatx4 (&v)[NT], gu32* status,
                        unsigned code) {
-    gu64* g = (gu64*)mbox;
     Spin s{status, (long long)wall_clock64(), 0u};
     for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < NT; i++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const unsigned long long x =
-                    __hip_atomic_load(g + granule_at(w + NW * i, r, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[i][r] = __uint_as_float((unsigned)x);
-                ok &= (unsigned)(x >> 32) == tag;
-            }
-        if (__all(ok)) return true;
+        unsigned long long q[NT * 4];
+        sweep_issue<NT, NW>(mbox, w, lane, q);
+        if (sweep_check<NT>(q, tag, v)) return true;
+        if (!spin_more(s, code)) return false;
+    }
+}
+// Latency-critical variant (the x hand-off): two passes in flight, a new one issued every WN_CHAIN_GAP sleeps,
+// so the time from the granules landing to their detection is a fraction of a memory round trip instead of
+// half a round trip on average.
+#ifndef WN_CHAIN_GAP
+#define WN_CHAIN_GAP 3
+#endif
+template <int NT, int NW>
+WN_DEV bool recv_tiles_fast(const unsigned long long* mbox, int w, int lane, unsigned tag, floatx4 (&v)[NT], gu32* status,
+                            unsigned code) {
+    Spin s{status, (long long)wall_clock64(), 0u};
+    unsigned long long qa[NT * 4], qb[NT * 4];
+    sweep_issue<NT, NW>(mbox, w, lane, qa);
+    for (;;) {
+        __builtin_amdgcn_s_sleep(WN_CHAIN_GAP);
+        sweep_issue<NT, NW>(mbox, w, lane, qb);
+        if (sweep_check<NT>(qa, tag, v)) return true;
+        __builtin_amdgcn_s_sleep(WN_CHAIN_GAP);
+        sweep_issue<NT, NW>(mbox, w, lane, qa);
+        if (sweep_check<NT>(qb, tag, v)) return true;
         if (!spin_more(s, code)) return false;
     }
 }
 
-// acc[mt] += W(tile slot mt) * b   with the stage's resident weights: fragment idx of the layer stream
-// sits in registers when idx < NRG, else in this wave's LDS slice (same order as gemm(), wn_kernels.hpp)
-template <bool F16, int NRG, int POS0, int MT, int KF>
-WN_DEV void gemm_rs(const typename Prec<F16>::frag (&wr)[NRG ? NRG : 1], const char* wl, unsigned laneOff, floatx4 (&acc)[MT],
-                    const typename Prec<F16>::frag (&b)[KF]) {
+// Placement exchange at the start of a launch: every stage publishes the XCD it runs on and reads its
+// consumer's.  A speed matter only: the answer selects the store flavour of send_tiles, both are valid.
+WN_DEV unsigned my_xcd() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu; }   // HW_REG_XCC_ID[3:0]
+WN_DEV bool chain_place(unsigned long long* place, int mine, int consumer, gu32* status, bool& sameXcd) {
+    gu64* g = (gu64*)place;
+    const unsigned xcd = my_xcd();
+    if (threadIdx.x == 0) __hip_atomic_store(g + mine, 0xC0DE00000000ull | xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Spin s{status, (long long)wall_clock64(), 0u};
+    for (;;) {
+        const unsigned long long c = __hip_atomic_load(g + consumer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((c >> 32) == 0xC0DEull) {
+            sameXcd = (unsigned)(c & 0xfu) == xcd;
+            return true;
+        }
+        if (!spin_more(s, 0x400u + (unsigned)mine)) return false;
+    }
+}
+
+// ---- weight fragments pinned in accumulator registers ---------------------------------------------------
+// An empty asm statement whose output is an "a"-class register tied to its input: the value is copied into
+// AGPRs once (4 v_accvgpr_write, in the prologue) and from then on IS an accumulator-file value; the MFMA
+// builtins take it as their A operand in place (v_mfma ... a[n:n+3], v[..], v[..]), with the compiler doing
+// the hazard bookkeeping as for any other operand.
+WN_DEV floatx4 agpr_pin(floatx4 v) {
+    floatx4 o;
+    asm volatile("" : "=a"(o) : "0"(v));
+    return o;
+}
+
+// acc[mt] += W(tile slot mt) * b  with AGPR-pinned fragments wres[pos0 ...] (the head's resident weights)
+template <bool F16, int MT, int KF, int NFR>
+WN_DEV void gemm_pinned(const floatx4 (&wres)[NFR], int pos0, floatx4 (&acc)[MT], const typename Prec<F16>::frag (&b)[KF]) {
+    using frag = typename Prec<F16>::frag;
+    constexpr int G = MT >= 4 ? 4 : MT;
+#pragma unroll
+    for (int mg = 0; mg < MT / G; mg++)
+#pragma unroll
+        for (int kf = 0; kf < KF; kf++)
+#pragma unroll
+            for (int mi = 0; mi < G; mi++)
+                acc[mg * G + mi] = mma(__builtin_bit_cast(frag, wres[pos0 + (mg * KF + kf) * G + mi]), b[kf], acc[mg * G + mi]);
+}
+
+// acc[mt] += W(tile slot mt) * b  with the stage's resident weights (fragment order of gemm(), wn_kernels.hpp).
+// CLS 0 = class A (cur: POS0 = 0, res: POS0 = FW_GATE), CLS 1 = class B (prev: POS0 = 0, skip: POS0 = FW_GATE).
+// A fragment at class position pos lives, in this order,  A: AGPR [0,NAA) | VGPR | LDS   B: AGPR | LDS | VGPR.
+template <bool F16, typename CC, int CLS, int POS0, int MT, int KF>
+WN_DEV void gemm_w(const floatx4 (&wag)[CC::NAG ? CC::NAG : 1], const typename Prec<F16>::frag (&wvg)[CC::NVG ? CC::NVG : 1],
+                   const char* wl, unsigned laneOff, floatx4 (&acc)[MT], const typename Prec<F16>::frag (&b)[KF]) {
     using frag = typename Prec<F16>::frag;
     constexpr int G = MT >= 4 ? 4 : MT;
 #pragma unroll
@@ -202,10 +334,17 @@ WN_DEV void gemm_rs(const typename Prec<F16>::frag (&wr)[NRG ? NRG : 1], const c
         for (int kf = 0; kf < KF; kf++)
 #pragma unroll
             for (int mi = 0; mi < G; mi++) {
-                const int idx = POS0 + (mg * KF + kf) * G + mi;
+                const int pos = POS0 + (mg * KF + kf) * G + mi;
                 frag a;
-                if (idx < NRG) a = wr[idx < NRG ? idx : 0];
-                else a = *(const frag*)(wl + (size_t)(idx - NRG) * 1024 + laneOff);
+                if (CLS == 0) {
+                    if (pos < CC::NAA) a = __builtin_bit_cast(frag, wag[pos < CC::NAA ? pos : 0]);
+                    else if (pos < CC::NAA + CC::NVA) a = wvg[pos < CC::NAA + CC::NVA ? pos - CC::NAA : 0];
+                    else a = *(const frag*)(wl + (size_t)(pos - CC::NAA - CC::NVA) * 1024 + laneOff);
+                } else {
+                    if (pos < CC::NAB) a = __builtin_bit_cast(frag, wag[pos < CC::NAB ? CC::NAA + pos : 0]);
+                    else if (pos < CC::NAB + CC::NLB) a = *(const frag*)(wl + (size_t)(CC::NLA + pos - CC::NAB) * 1024 + laneOff);
+                    else a = wvg[pos >= CC::NAB + CC::NLB ? CC::NVA + pos - CC::NAB - CC::NLB : 0];
+                }
                 acc[mg * G + mi] = mma(a, b[kf], acc[mg * G + mi]);
             }
 }
@@ -220,13 +359,12 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
     using P = Prec<F16>;
     using frag = typename P::frag;
     using elem = typename P::elem;
-    constexpr int LP = CC::LP, NRG = CC::NRG, NLD = CC::NLD, NW = C::NW, FLW = C::FLW;
+    constexpr int LP = CC::LP, NLD = CC::NLD, NW = C::NW, FLW = C::FLW;
     constexpr int RT = C::RT, HTW = C::HTW, STW = C::STW, KF_R = C::KF_R;
 
     char* const xbuf = lds + CC::OFF_LX;
     char* const hbuf = lds + CC::OFF_LH;
-    float* const biasLds = (float*)(lds + CC::OFF_LB);          // [LP][BIAS_L] then [LP][S] running skip bias
-    float* const rsb = biasLds + LP * C::BIAS_L;
+    float* const biasLds = (float*)(lds + CC::OFF_LB);          // [LP][Bh 2R | Bres R]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -244,38 +382,43 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
     const int ub = uvalid ? b : p.batch - 1;
 
     // mailboxes: this stage's inputs, the next stage's inputs
-    unsigned long long* const mbase = cp.mail + ((size_t)chainIdx * cp.stages + stage) * (CC::XG + CC::SG);
+    unsigned long long* const boxes = cp.mail + CC::placeWords(cp.chains, cp.stages);
+    unsigned long long* const mbase = boxes + ((size_t)chainIdx * cp.stages + stage) * (CC::XG + CC::SG);
     const unsigned long long* const xin = mbase;
     const unsigned long long* const skin = mbase + CC::XG;
     unsigned long long* const xout = mbase + (CC::XG + CC::SG);
     unsigned long long* const skout = xout + CC::XG;
     gu32* const status = (gu32*)cp.status;
+    bool sameXcd = false;
+    if (!chain_place(cp.mail, chainIdx * cp.stages + stage, chainIdx * cp.stages + stage + 1, status, sameXcd)) return;
 
-    // ---- biases of the own layers -> LDS; running skip-bias sums (dump only) ---------------------
-    for (int i = tid; i < nl * C::BIAS_L; i += C::THREADS) biasLds[i] = p.bias[(size_t)l0 * C::BIAS_L + i];
-    if (DUMP) {
-        for (int s0 = tid; s0 < S; s0 += C::THREADS) {
-            float run = 0.f;
-            for (int l = 0; l < l0 + nl; l++) {
-                const float bl = p.bias[(size_t)l * C::BIAS_L + 3 * R + s0];
-                run = l == 0 ? bl : run + bl;                  // layer order, like wavenet_wg
-                if (l >= l0) rsb[(l - l0) * S + s0] = run;
-            }
-        }
-    }
+    // ---- gate and residual biases of the own layers -> LDS (the skip biases are added by the head) ----
+    for (int i = tid; i < nl * 3 * R; i += C::THREADS)
+        biasLds[i] = p.bias[(size_t)(l0 + i / (3 * R)) * C::BIAS_L + i % (3 * R)];
 
-    // ---- resident weights: head of every layer's stream -> registers, tail -> this wave's LDS slice ----
+    // ---- resident weights (per layer stream: prev | cur | res | skip) ---------------------------------
     const char* const wbase = (const char*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 1024;
-    frag wr[LP][NRG ? NRG : 1];
+    floatx4 wag[LP][CC::NAG ? CC::NAG : 1];   // AGPRs: [class A | class B]
+    frag wvg[LP][CC::NVG ? CC::NVG : 1];      // VGPRs: [class A | class B]
 #pragma unroll
     for (int li = 0; li < LP; li++) {
         const char* wl = wbase + (size_t)(l0 + (li < nl ? li : 0)) * FLW * 1024;
+        char* const myl = wlds + (size_t)li * NLD * 1024;
 #pragma unroll
-        for (int i = 0; i < NRG; i++) wr[li][i] = *(const frag*)(wl + (size_t)i * 1024 + laneOff);
-        if (li < nl) {
+        for (int a = 0; a < CC::FA; a++) {                 // class A: cur | res are contiguous in the stream
+            const frag f = *(const frag*)(wl + (size_t)(C::O_CUR + a) * 1024 + laneOff);
+            if (a < CC::NAA) wag[li][a < CC::NAA ? a : 0] = agpr_pin(__builtin_bit_cast(floatx4, f));
+            else if (a < CC::NAA + CC::NVA) wvg[li][a < CC::NAA + CC::NVA ? a - CC::NAA : 0] = f;
+            else if (li < nl) *(frag*)(myl + (size_t)(a - CC::NAA - CC::NVA) * 1024 + laneOff) = f;
+        }
 #pragma unroll
-            for (int i = 0; i < NLD; i++)
-                *(frag*)(wlds + (size_t)(li * NLD + i) * 1024 + laneOff) = *(const frag*)(wl + (size_t)(NRG + i) * 1024 + laneOff);
+        for (int bq = 0; bq < CC::FB; bq++) {              // class B: prev, then skip
+            const int idx = bq < C::FW_GATE ? C::O_PREV + bq : C::O_SKIP + (bq - C::FW_GATE);
+            const frag f = *(const frag*)(wl + (size_t)idx * 1024 + laneOff);
+            if (bq < CC::NAB) wag[li][bq < CC::NAB ? CC::NAA + bq : 0] = agpr_pin(__builtin_bit_cast(floatx4, f));
+            else if (bq < CC::NAB + CC::NLB) {
+                if (li < nl) *(frag*)(myl + (size_t)(CC::NLA + bq - CC::NAB) * 1024 + laneOff) = f;
+            } else wvg[li][bq >= CC::NAB + CC::NLB ? CC::NVA + bq - CC::NAB - CC::NLB : 0] = f;
         }
     }
 
@@ -314,19 +457,32 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
 
         // ---- while the sample is on its way: conditioning + dilated-tap GEMMs of all own layers ------
         floatx4 acc[LP][2 * HTW];
-        frag cd[LP][C::COND_FR];
 #pragma unroll
         for (int li = 0; li < LP; li++) {
             if (li < nl) {
+                frag cd[1][C::COND_FR];
                 const int l = l0 + li;
-                const float* bl = biasLds + li * C::BIAS_L;
+                const float* bl = biasLds + li * 3 * R;
                 const char* cp0 = condMine + ((size_t)t * L + l) * condStride;
 #pragma unroll
-                for (int k = 0; k < C::COND_FR; k++) cd[li][k] = *(const frag*)(cp0 + k * 1024 + laneOff);
+                for (int k = 0; k < C::COND_FR; k++) cd[0][k] = *(const frag*)(cp0 + k * 1024 + laneOff);
 #pragma unroll
                 for (int i = 0; i < HTW; i++) {
                     acc[li][2 * i] = *(const floatx4*)(bl + (w + NW * i) * 16 + g * 4);
                     acc[li][2 * i + 1] = *(const floatx4*)(bl + (w + NW * i + RT) * 16 + g * 4);
+                }
+                // + conditioning (fp16: a B-layout fragment added by the matrix core through a 0/1 selection matrix)
+                if constexpr (F16) {
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                        for (int tt = 0; tt < P::TPF; tt++)
+                            acc[li][k * P::TPF + tt] = mma(selA[tt], cd[0][k], acc[li][k * P::TPF + tt]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                        for (int e = 0; e < P::EPL; e++) acc[li][k * P::TPF + (e >> 2)][e & 3] += (float)cd[0][k][e];
                 }
                 const int d = dl[li].d;
                 const bool havePrev = t >= d;
@@ -340,14 +496,15 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
                         for (int e = 0; e < P::EPL; e++) xp[k][e] = (elem)0.f;
                     }
                 }
-                gemm_rs<F16, NRG, C::O_PREV, 2 * HTW, KF_R>(wr[li], wlds + (size_t)li * NLD * 1024, laneOff, acc[li], xp);
+                gemm_w<F16, CC, 1, 0, 2 * HTW, KF_R>(wag[li], wvg[li], wlds + (size_t)li * NLD * 1024, laneOff, acc[li], xp);
             }
         }
 
         // ---- the sample arrives: x_l0[t], this wave's tiles (fp32) ----------------------------------
         floatx4 x[HTW];
         WN_CT(1)
-        if (!recv_tiles<HTW, NW>(xin, w, lane, tag, x, status, 0x100u + (unsigned)stage)) return;
+        if (!recv_tiles_fast<HTW, NW>(xin, w, lane, tag, x, status, 0x100u + (unsigned)stage)) return;
+        unsigned long long skq[STW * 4];
         WN_CT(2)
 #pragma unroll
         for (int i = 0; i < HTW; i++) lds_put_tile<F16>(xbuf, w + NW * i, lane, x[i]);
@@ -357,7 +514,7 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
         for (int li = 0; li < LP; li++) {
             if (li < nl) {
                 const int l = l0 + li;
-                const float* bl = biasLds + li * C::BIAS_L;
+                const float* bl = biasLds + li * 3 * R;
                 const char* wl = wlds + (size_t)li * NLD * 1024;
                 char* const hb_img = hbuf + li * C::HBUF;
                 frag xb[KF_R];
@@ -368,24 +525,16 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
                     const int d = dl[li].d;
                     char* rp = ringMine + (size_t)(unsigned)(dl[li].off + (t & (d - 1))) * (KF_R * 1024);
 #pragma unroll
-                    for (int k = 0; k < KF_R; k++)
-                        if (k % NW == w) *(frag*)(rp + (size_t)k * 1024 + laneOff) = xb[k];
+                    for (int i = 0; i < C::XPW; i++) {
+                        const int k = w + NW * i;          // wave-uniform: no select over the xb registers
+                        if (k < KF_R) *(frag*)(rp + (size_t)k * 1024 + laneOff) = *(const frag*)(xbuf + (size_t)k * 1024 + laneOff);
+                    }
                 }
-                gemm_rs<F16, NRG, C::O_CUR, 2 * HTW, KF_R>(wr[li], wl, laneOff, acc[li], xb);
-                if constexpr (F16) {
-#pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int tt = 0; tt < P::TPF; tt++)
-                            acc[li][k * P::TPF + tt] = mma(selA[tt], cd[li][k], acc[li][k * P::TPF + tt]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int e = 0; e < P::EPL; e++) acc[li][k * P::TPF + (e >> 2)][e & 3] += (float)cd[li][k][e];
-                }
+                gemm_w<F16, CC, 0, 0, 2 * HTW, KF_R>(wag[li], wvg[li], wl, laneOff, acc[li], xb);
                 if (li == 0) {
+#ifdef WN_CHAIN_TIMING
                     asm volatile("s_nop 0" ::"v"(acc[li][0][0]), "v"(acc[li][1][0]));
+#endif
                     WN_CT(9)
                 }
 #pragma unroll
@@ -399,14 +548,19 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
                 frag hb[KF_R];
                 lds_get_frags<F16, KF_R>(hb_img, lane, hb);
                 if (li == 0) WN_CT(12)
+                // the skip sums of the stage before are usually on their way by now: the first sweep pass for them
+                // is issued here, behind the last own layer's residual GEMM, instead of after the x hand-off
+                if (li + 1 == nl && stage != 0) sweep_issue<STW, NW>(skin, w, lane, skq);
                 floatx4 xa[HTW];
 #pragma unroll
                 for (int i = 0; i < HTW; i++) xa[i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[i];
-                gemm_rs<F16, NRG, C::O_RES, HTW, KF_R>(wr[li], wl, laneOff, xa, hb);
+                gemm_w<F16, CC, 0, C::FW_GATE, HTW, KF_R>(wag[li], wvg[li], wl, laneOff, xa, hb);
 #pragma unroll
                 for (int i = 0; i < HTW; i++) x[i] = xa[i];
                 if (li == 0) {
+#ifdef WN_CHAIN_TIMING
                     asm volatile("s_nop 0" ::"v"(x[0][0]));
+#endif
                     WN_CT(13)
                 }
                 if (dumpNow && uvalid) {
@@ -423,7 +577,7 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
             }
         }
         WN_CT(3)
-        if (!lastLayerStage) send_tiles<HTW, NW>(xout, w, lane, tag, x);   // (the last layer's output is unused)
+        if (!lastLayerStage) send_tiles<HTW, NW>(xout, w, lane, tag, x, sameXcd);   // (the last layer's output is unused)
         WN_CT(4)
 
         // ---- behind the sample: running skip sums  skip <- Wskip_l h_l + skip  ------------------------
@@ -431,26 +585,31 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
         if (stage == 0) {
 #pragma unroll
             for (int i = 0; i < STW; i++) sk[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-        } else if (!recv_tiles<STW, NW>(skin, w, lane, tag, sk, status, 0x200u + (unsigned)stage)) return;
+        } else if (!sweep_check<STW>(skq, tag, sk)) {
+            if (!recv_tiles<STW, NW>(skin, w, lane, tag, sk, status, 0x200u + (unsigned)stage)) return;
+        }
         WN_CT(5)
 #pragma unroll
         for (int li = 0; li < LP; li++) {
             if (li < nl) {
                 frag hb[KF_R];
                 lds_get_frags<F16, KF_R>(hbuf + li * C::HBUF, lane, hb);
-                gemm_rs<F16, NRG, C::O_SKIP, STW, KF_R>(wr[li], wlds + (size_t)li * NLD * 1024, laneOff, sk, hb);
+                gemm_w<F16, CC, 1, C::FW_GATE, STW, KF_R>(wag[li], wvg[li], wlds + (size_t)li * NLD * 1024, laneOff, sk, hb);
                 // (the last layer's skipOut is dumped by the head, after the ReLU)
                 if (dumpNow && uvalid && l0 + li < L - 1) {
-                    const float* bp = rsb + li * S;
 #pragma unroll
-                    for (int i = 0; i < STW; i++)
-                        *(floatx4*)(p.skipOut + ((size_t)(l0 + li) * p.maxBatch + ub) * S + (w + NW * i) * 16 + g * 4) =
-                            sk[i] + *(const floatx4*)(bp + (w + NW * i) * 16 + g * 4);
+                    for (int i = 0; i < STW; i++) {
+                        // running sum of the skip biases up to this layer, in layer order like wavenet_wg
+                        const int row = (w + NW * i) * 16 + g * 4;
+                        floatx4 run = *(const floatx4*)(p.bias + 3 * R + row);
+                        for (int l = 1; l <= l0 + li; l++) run += *(const floatx4*)(p.bias + (size_t)l * C::BIAS_L + 3 * R + row);
+                        *(floatx4*)(p.skipOut + ((size_t)(l0 + li) * p.maxBatch + ub) * S + row) = sk[i] + run;
+                    }
                 }
             }
         }
         WN_CT(6)
-        send_tiles<STW, NW>(skout, w, lane, tag, sk);
+        send_tiles<STW, NW>(skout, w, lane, tag, sk, sameXcd);
         WN_CT(7)
         WN_CT_FLUSH(stage, t - p.initSample)
     }
@@ -493,10 +652,13 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
     const int ub = uvalid ? b : p.batch - 1;
     const int su = tid / C::LPU, sq = tid % C::LPU;            // softmax role
 
-    unsigned long long* const mbase = cp.mail + ((size_t)chainIdx * cp.stages + stage) * (CC::XG + CC::SG);
+    unsigned long long* const boxes = cp.mail + CC::placeWords(cp.chains, cp.stages);
+    unsigned long long* const mbase = boxes + ((size_t)chainIdx * cp.stages + stage) * (CC::XG + CC::SG);
     const unsigned long long* const skin = mbase + CC::XG;
-    unsigned long long* const xout = cp.mail + ((size_t)chainIdx * cp.stages) * (CC::XG + CC::SG);   // stage 0
+    unsigned long long* const xout = boxes + ((size_t)chainIdx * cp.stages) * (CC::XG + CC::SG);   // stage 0
     gu32* const status = (gu32*)cp.status;
+    bool sameXcd = false;
+    if (!chain_place(cp.mail, chainIdx * cp.stages + stage, chainIdx * cp.stages, status, sameXcd)) return;
 
     // ---- biases: sum of all skip biases (layer order, like wavenet_wg's running sums), Bzs, Bza ----
     for (int s0 = tid; s0 < S; s0 += C::THREADS) {
@@ -532,10 +694,12 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
     // ---- head weights: resident fragments, prefetch ring for the streamed part ---------------------
     const char* const wbase = (const char*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 1024;
     const char* const whead = wbase + C::headOffsetFrags(L) * 1024;
-    frag hw[HR ? HR : 1];
+    // resident head fragments: pinned in the accumulator file, read in place by the MFMAs (agpr_pin)
+    floatx4 hw[HR ? HR : 1];
     if constexpr (HR > 0) {
 #pragma unroll
-        for (int i = 0; i < HR; i++) hw[i] = *(const frag*)(whead + (size_t)(HS + i) * 1024 + laneOff);
+        for (int i = 0; i < HR; i++)
+            hw[i] = agpr_pin(__builtin_bit_cast(floatx4, *(const frag*)(whead + (size_t)(HS + i) * 1024 + laneOff)));
     }
     WStream<F16, PF> ws;
     if constexpr (HS > 0) {
@@ -548,19 +712,24 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
     __syncthreads();   // tables and biases complete
 
     // embedding of the sample after (yPrev, yCur) -> stage 0 (nv_wavenet_reference.cpp:42-56)
+    // ep: the older tap's row of the NEXT sample is the current tap's index of this one: gathered a whole
+    // sample early (it may come from global memory when only one table fits in LDS)
+    floatx4 ep[HTW];
+#pragma unroll
+    for (int i = 0; i < HTW; i++) ep[i] = rowPrev(yPrev, w + NW * i);
     auto embed_and_send = [&](unsigned tag) {
         floatx4 x0[HTW];
 #pragma unroll
         for (int i = 0; i < HTW; i++) {
             const int tile16 = w + NW * i;
-            floatx4 v = rowPrev(yPrev, tile16) + rowCur(yCur, tile16);
+            floatx4 v = ep[i] + rowCur(yCur, tile16);
             if (p.tanhEmbed) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = tanh_t<F16>(v[r]);
             }
             x0[i] = v;
         }
-        send_tiles<HTW, NW>(xout, w, lane, tag, x0);
+        send_tiles<HTW, NW>(xout, w, lane, tag, x0, sameXcd);
     };
     embed_and_send(1u);
 
@@ -575,10 +744,12 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
                                     : p.sel[(size_t)t * p.maxBatch + sb];
 
         // ---- skip sums of all layers arrive; + biases, ReLU -> B fragments -----------------------------
+#pragma unroll
+        for (int i = 0; i < HTW; i++) ep[i] = rowPrev(yCur, w + NW * i);   // for the sample after this one
         floatx4 sk[STW];
         WN_CT_DECL
         WN_CT(0)
-        if (!recv_tiles<STW, NW>(skin, w, lane, tag, sk, status, 0x300u)) return;
+        if (!recv_tiles_fast<STW, NW>(skin, w, lane, tag, sk, status, 0x300u)) return;
         WN_CT(1)
 #pragma unroll
         for (int i = 0; i < STW; i++) {
@@ -596,7 +767,7 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
             lds_get_frags<F16, KF_S>(skbuf, lane, sbf[0]);
 #pragma unroll
             for (int i = 0; i < ATW; i++) zs[0][i] = *(const floatx4*)(headBias + (w + NW * i) * 16 + g * 4);
-            if constexpr (HS == 0) gemm_res<F16, 1, ATW, KF_S>(hw, 0, zs, sbf);
+            if constexpr (HS == 0) gemm_pinned<F16, ATW, KF_S>(hw, 0, zs[0], sbf[0]);
             else gemm<F16, PF, HS, 1, ATW, KF_S>(ws, 0, whead, whead, laneOff, zs, sbf);
         }
 #pragma unroll
@@ -617,7 +788,7 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
             } else {
                 frag zb[1][KF_A];
                 lds_get_frags<F16, KF_A>(zsbuf, lane, zb[0]);
-                if constexpr (HR >= C::FW_ZA) gemm_res<F16, 1, ATW, KF_A>(hw, C::FW_ZS - HS, za, zb);
+                if constexpr (HR >= C::FW_ZA) gemm_pinned<F16, ATW, KF_A>(hw, C::FW_ZS - HS, za[0], zb[0]);
                 else gemm<F16, PF, HS, 1, ATW, KF_A>(ws, C::FW_ZS, whead, whead, laneOff, za, zb);
             }
             if constexpr (C::ALIAS_LG) wg_barrier();   // every wave is done with the zs image

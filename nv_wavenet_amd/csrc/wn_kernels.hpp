@@ -800,6 +800,26 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     acc[bt][2 * i + 1] = *(const floatx4*)(bl + (w + NW * i + RT) * 16 + g * 4);
                 }
             }
+            // + conditioning (summation order of the gate pre-activation in every organisation of the engine:
+            // bias, conditioning, dilated tap, current tap -- the multi-CU chain forms the first three while it
+            // waits for the sample).  fp16: a fragment in B layout already, added by the matrix core through a
+            // 0/1 selection matrix (2 MFMAs instead of 8 conversions + 8 adds per fragment)
+            if constexpr (F16) {
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                        for (int tt = 0; tt < P::TPF; tt++)
+                            acc[bt][k * P::TPF + tt] = mma(selA[tt], cdC[bt][k], acc[bt][k * P::TPF + tt]);
+            } else {
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                        for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cdC[bt][k][e];
+            }
             // deferred skip GEMM of the previous layer: skip <- Wskip h + skip
             if constexpr (SKIP) {
                 gemm<F16, PF, 0, BT, STW, KF_R>(ws, C::O_SKIP, wl, wl, laneOff, skip, hb, wrapAt, wrapDelta);
@@ -840,24 +860,6 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     if (k % NW == w) st_stream((frag*)(rp + k * 1024 + laneOff), xb[bt][k], nt);
             }
             gemm<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, OFS + C::O_CUR, wl, wl, laneOff, acc, xb, wrapAt, wrapDelta);
-            if constexpr (F16) {
-                // conditioning: a fragment in B layout already, added by the matrix core through a
-                // 0/1 selection matrix (2 MFMAs instead of 8 conversions + 8 adds per fragment)
-#pragma unroll
-                for (int bt = 0; bt < BT; bt++)
-#pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int tt = 0; tt < P::TPF; tt++)
-                            acc[bt][k * P::TPF + tt] = mma(selA[tt], cdC[bt][k], acc[bt][k * P::TPF + tt]);
-            } else {
-#pragma unroll
-                for (int bt = 0; bt < BT; bt++)
-#pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cdC[bt][k][e];
-            }
 #ifndef WN_PREFETCH_LATE
             // VMEM returns in order: the first weight fragment requested AFTER these HBM loads is taken
             // by the next layer's GEMMs, so issuing them here, ahead of the take-free gate / exchange
