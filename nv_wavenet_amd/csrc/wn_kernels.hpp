@@ -473,8 +473,36 @@ WN_DEV void gemm_res(const typename Prec<F16>::frag (&wres)[NFR], int pos0, floa
 // "sel < cumulative p"), or 128 when the scan falls off the end (softmax.cuh:154-155).  e[] receives
 // this lane's exp(logit - max) values and `total` their sum over the group (for the probability dump).
 // ------------------------------------------------------------------------------------------
+// Cross-lane steps inside one 16-lane DPP row (LPU <= 16 lanes serve an utterance): data-parallel-primitive
+// moves on the VALU operand path instead of __shfl_* (ds_bpermute: an LDS-crossbar round trip of ~100 clk
+// each, 12 of them per pick = half of the 1 us this function took).
+template <int CTRL> WN_DEV float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> WN_DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;              // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;   // lane i <-> 7-i (in 8), i <-> 15-i (in 16)
+// all-reduce of a commutative, associative, EXACT op (max / min) over the LPU lanes of a group: butterflies
+// inside the quads, then mirrors (a lane's mirror partner holds the other half's result)
+template <int LPU, typename F> WN_DEV float group_reduce_f(float v, F op) {
+    static_assert(LPU == 4 || LPU == 8 || LPU == 16, "softmax lanes per utterance");
+    v = op(v, dpp_f<DPP_XOR1>(v));
+    v = op(v, dpp_f<DPP_XOR2>(v));
+    if (LPU >= 8) v = op(v, dpp_f<DPP_HALF_MIRROR>(v));
+    if (LPU >= 16) v = op(v, dpp_f<DPP_MIRROR>(v));
+    return v;
+}
+template <int LPU> WN_DEV int group_min_i(int v) {
+    int o = dpp_i<DPP_XOR1>(v); v = o < v ? o : v;
+    o = dpp_i<DPP_XOR2>(v); v = o < v ? o : v;
+    if (LPU >= 8) { o = dpp_i<DPP_HALF_MIRROR>(v); v = o < v ? o : v; }
+    if (LPU >= 16) { o = dpp_i<DPP_MIRROR>(v); v = o < v ? o : v; }
+    return v;
+}
+
 template <int A, int LPU, int RPL>
 WN_DEV int softmax_pick(const float* lrow, int sq, int lane, float sel, float (&e)[RPL], float& total) {
+    (void)lane;
 #pragma unroll
     for (int i = 0; i < RPL / 4; i++) {
         floatx4 v = *(const floatx4*)(lrow + i * 4);
@@ -484,22 +512,31 @@ WN_DEV int softmax_pick(const float* lrow, int sq, int lane, float sel, float (&
     float m = e[0];
 #pragma unroll
     for (int i = 1; i < RPL; i++) m = __builtin_fmaxf(m, e[i]);
-#pragma unroll
-    for (int o = 1; o < LPU; o <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+    m = group_reduce_f<LPU>(m, [](float a, float b) { return __builtin_fmaxf(a, b); });
     float lsum = 0.f;
 #pragma unroll
     for (int i = 0; i < RPL; i++) {
         e[i] = fast_exp(e[i] - m);
         lsum += e[i];
     }
-    // inclusive scan of the lane sums over the LPU lanes of this utterance
+    // inclusive scan of the lane sums over the LPU lanes of this utterance (row_shr:o reads lane - o of the row)
     float incl = lsum;
-#pragma unroll
-    for (int o = 1; o < LPU; o <<= 1) {
-        float up = __shfl_up(incl, o);
-        if (sq >= o) incl += up;
+    {
+        float up = dpp_f<0x111>(incl);
+        if (sq >= 1) incl += up;
+        up = dpp_f<0x112>(incl);
+        if (sq >= 2) incl += up;
+        if (LPU >= 8) {
+            up = dpp_f<0x114>(incl);
+            if (sq >= 4) incl += up;
+        }
+        if (LPU >= 16) {
+            up = dpp_f<0x118>(incl);
+            if (sq >= 8) incl += up;
+        }
     }
-    total = __shfl(incl, (lane & ~(LPU - 1)) + LPU - 1);
+    // the group's total is its last lane's inclusive sum = the largest of the (non-decreasing) prefix sums
+    total = group_reduce_f<LPU>(incl, [](float a, float b) { return __builtin_fmaxf(a, b); });
     const float target = sel * total;
     // first row of this lane whose cumulative sum exceeds the target
     float cum = incl - lsum;   // exclusive prefix of this lane
@@ -510,11 +547,7 @@ WN_DEV int softmax_pick(const float* lrow, int sq, int lane, float sel, float (&
         first = (first == RPL && target < cum) ? i : first;
     }
     int pick = first < RPL ? sq * RPL + first : 0x7fffffff;
-#pragma unroll
-    for (int o = 1; o < LPU; o <<= 1) {
-        int other = __shfl_xor(pick, o);
-        pick = other < pick ? other : pick;
-    }
+    pick = group_min_i<LPU>(pick);
     if (pick >= A) pick = 128;             // scan fell off the end (softmax.cuh:154-155)
     return pick;
 }

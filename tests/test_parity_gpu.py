@@ -35,8 +35,10 @@ def _check_mode(e, mode, shape):
     if mode in ("chain", "chain1") and shape.R >= 256:
         assert "wavenet_wg<" in info, info
         return
+    if mode == "stream" and "wavenet_wg<" in info:
+        return   # shapes whose LDS ring has fewer than 5 slots beside the bias table run the latency kernel instead
     assert KERNEL_OF[mode] in info, (mode, info)
-    if mode == "wg2":
+    if mode == "wg2" and shape.R < 128:   # (two tiles of R >= 128 do not fit the LDS of one workgroup: one tile runs)
         assert "BT=2" in info, info
     if mode == "chain1":
         assert "layers/stage=1 " in info, info
