@@ -6,12 +6,22 @@ Metric (BASELINE.json): samples/sec/GPU and max real-time batch @24 kHz at R=64/
 SAMPLES_PER_STEP samples for every utterance of the batch (synthetic conditioning / selectors /
 random-init weights already resident in HBM).  `value` = utterances x samples / second over all
 GPUs, measured at the largest batch whose per-utterance rate stays >= 24 kHz (found by a bounded
-sweep before the timed region; override with --batch).  The literal configs[2] point (batch 16)
-is reported beside it as `c3_b16`.
+bisection over the number of 16-utterance tiles before the timed region; override with --batch).
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one process per GPU): utterances shard
-with no data-path collective (weak scaling: every GPU runs the same per-GPU batch); each step
-ends with ONE RCCL all_gather of the [B/G][N] int32 sample blocks, overlapped with the next step.
+Beside it (rank 0, N = 1 only) the reference's own measurement is reproduced for the BASELINE configs
+C2 / C3 / C4 (`reference_definition`): nv_wavenet_perf.cu:67-87 -- 16 384 samples through run_chunks in
+chunks of 2 048 with the per-chunk copies of the samples to pinned host memory inside the timed region,
+kHz per utterance = samples / elapsed ms -- for the single-workgroup and the multi-CU organisation; and
+`end_to_end`: the largest real-time batch when the conditioning is NOT pre-packed but streamed chunk by
+chunk (fp32 [N][L][B][2R] on the device -> fragment order, packed on a second stream behind the
+generation of the previous chunk).
+
+Multi-GPU: `python bench.py --gpus N` spawns its own N ranks (torch.distributed.run, one process per
+GPU, 127.0.0.1 rendezvous) unless it already runs under a launcher (WORLD_SIZE set).  Utterances shard
+with no data-path collective (weak scaling: every GPU runs the same per-GPU batch; `--config c5`: the
+BASELINE C5 point, global batch 64 split over the ranks); each step ends with ONE RCCL all_gather of
+the [B/G][N] int32 sample blocks, overlapped with the next step.  n_gpus is reported only after an
+all_gather of the ranks' device ids proved that N distinct processes took part.
 
 Timing: W warm-up steps, then barrier + synchronize, K timed steps, synchronize + barrier, MAX
 over ranks.  The dominant kernel's launch duration is measured live with HIP events on the stream
@@ -22,6 +32,7 @@ bounded sample of the same workload shape (rank 0, N=1 only).
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -30,22 +41,37 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-R, S, A, L, MAXD = 64, 256, 256, 20, 512      # BASELINE.json configs[2] shape (C3)
 REALTIME_KHZ = 24.0
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0                 # dense fp16/bf16 MFMA peak
 L2_PEAK_GBS = 34500.0                         # aggregate L2 bandwidth (guide, measured)
 LDS_PEAK_GBS = 256 * 256 * 2.4                # 256 B/clk/CU x 256 CUs x 2.4 GHz (guide, LDS section)
 
-# algorithmic work per sample per utterance (SURVEY.md 8d / BASELINE.md)
-MACS = L * (5 * R * R + S * R) + A * S + A * A
-FLOPS = 2 * MACS
-WEIGHT_BYTES = 2 * (L * (5 * R * R + S * R) + A * S + A * A)     # fp16 weights streamed per tile pass
-HBM_BYTES = 2 * 2 * R * L + 4 + 4                                # cond (fp16) + selector + yOut
+
+class Shape:
+    """A BASELINE.json config: channel counts, depth, dilation range."""
+
+    def __init__(self, name, R, S, A, L, maxD, B):
+        self.name, self.R, self.S, self.A, self.L, self.maxD, self.B = name, R, S, A, L, maxD, B
+        # algorithmic work per sample per utterance (SURVEY.md 8d / BASELINE.md)
+        self.macs = L * (5 * R * R + S * R) + A * S + A * A
+        self.flops = 2 * self.macs
+        self.weight_bytes = 2 * self.macs                 # fp16 weights touched per tile pass
+        self.hbm_bytes = 2 * 2 * R * L + 4 + 4            # cond (fp16) + selector + yOut
+
+
+C2 = Shape("C2", 64, 128, 256, 20, 512, 4)
+C3 = Shape("C3", 64, 256, 256, 20, 512, 16)
+C4 = Shape("C4", 128, 256, 256, 30, 512, 8)
+HEAD = C3                                     # the shape the headline metric is quoted on
+R, S, A, L, MAXD = HEAD.R, HEAD.S, HEAD.A, HEAD.L, HEAD.maxD
+# the device code the engine launches for the headline point (asserted against nvw_kernel_info, and pinned
+# by tests/test_parity_gpu.py::test_benchmarked_launch_*: the timed kernel is the parity-tested one)
+HEADLINE_KERNEL = "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=1,DUMP=0>"
 
 
 def lds_bytes_per_sample(stream_mode, bt=1):
-    """Algorithmic LDS bytes moved per generated sample per WORKGROUP (fp16).
+    """Algorithmic LDS bytes moved per generated sample per WORKGROUP (C3 shape, fp16).
     wg kernel (4 waves on bt tiles): per layer every wave reads the x, x[t-d] and h fragment images
     (R/32 KiB each) and its bias quads, and writes its quarter of h, x and the dilated tap; the head
     moves skip / zs images (S/32, A/32 KiB, read by all 4 waves) and the fp32 logits once each way.
@@ -53,16 +79,17 @@ def lds_bytes_per_sample(stream_mode, bt=1):
     by LDS-DMA and read once by every consumer; activations never leave registers."""
     kf = lambda n: n // 32 * 1024
     if stream_mode:
-        return 5 * WEIGHT_BYTES + 4 * (16 * A * 4 * 2)
+        return 5 * HEAD.weight_bytes + 4 * (16 * A * 4 * 2)
     per_layer = bt * (4 * 3 * kf(R) + 3 * kf(R)) + 4 * 64 * 16 * 3        # exchanges + bias quads
     head = bt * (5 * kf(S) + 5 * kf(A) + 2 * 16 * A * 4 + 2 * kf(R)) + 4 * 64 * 16 * (S // 64 + 2 * A // 64)
     return L * per_layer + head
 
 
-def make_weights(seed=3):
+def make_weights(sh=HEAD, seed=3):
     """The parity recipe of nv_wavenet_test.cu:36-111: uniform +-0.25/R for embeddings, output head;
     +-0.25/rows for per-layer matrices and biases."""
     rng = np.random.default_rng(seed)
+    R, S, A, L = sh.R, sh.S, sh.A, sh.L
     u = lambda sc, *s: ((rng.random(s, dtype=np.float32) - 0.5) * sc).astype(np.float32)
     w = dict(embP=u(0.5 / R, A, R), embC=u(0.5 / R, A, R),
              Wprev=u(0.25 / R, L, R, 2 * R), Wcur=u(0.25 / R, L, R, 2 * R), Bh=u(0.25 / R, L, 2 * R),
@@ -71,24 +98,25 @@ def make_weights(seed=3):
     return w
 
 
-def build_engine(w, B, N, precision=16):
+def build_engine(w, B, N, sh=HEAD, precision=16, impl=0, organisation=0):
     from nv_wavenet_amd import WavenetEngine
-    e = WavenetEngine(R, S, A, L, MAXD, B, N, impl=3, tanhEmbed=True, precision=precision)
+    e = WavenetEngine(sh.R, sh.S, sh.A, sh.L, sh.maxD, B, N, impl=impl, tanhEmbed=True, precision=precision,
+                      organisation=organisation)
     e.setEmbeddings(w["embP"], w["embC"])
-    for l in range(L):
+    for l in range(sh.L):
         e.setLayerWeights(l, w["Wprev"][l], w["Wcur"][l], w["Bh"][l], w["Wres"][l], w["Bres"][l], w["Wskip"][l],
                           w["Bskip"][l])
     e.setOutWeights(w["Wzs"], w["Bzs"], w["Wza"], w["Bza"])
     return e
 
 
-def device_inputs(B, N, seed):
+def device_inputs(B, N, seed, sh=HEAD):
     """Synthetic conditioning [N][L][B][2R] (uniform +-0.25/R) and selectors [N][B] in HBM."""
     import torch
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
-    Lh = torch.empty(N, L, B, 2 * R, dtype=torch.float32, device="cuda")
-    Lh.uniform_(-0.25 / R, 0.25 / R, generator=g)
+    Lh = torch.empty(N, sh.L, B, 2 * sh.R, dtype=torch.float32, device="cuda")
+    Lh.uniform_(-0.25 / sh.R, 0.25 / sh.R, generator=g)
     sel = torch.rand(N, B, dtype=torch.float32, device="cuda", generator=g)
     return Lh, sel
 
@@ -101,29 +129,95 @@ def samples_per_step_for(B):
     return n
 
 
-def measure_khz(w, B, N, seed=11, mode=None):
-    """per-utterance kHz of one launch at batch B (HIP events on the launch stream).
-    mode: None = the engine's own choice; "wg" / "stream" force a kernel organisation."""
+def measure_khz(w, B, N, seed=11, organisation=0):
+    """per-utterance kHz of one launch at batch B with pre-packed conditioning (HIP events on the launch
+    stream).  organisation: 0 = the engine's own choice, else a forced nvwOrganisation."""
     import torch
-    old = os.environ.get("NVW_MODE")
-    if mode:
-        os.environ["NVW_MODE"] = mode
-    try:
-        e = build_engine(w, B, N)
-    finally:
-        if mode:
-            os.environ.pop("NVW_MODE", None)
-            if old is not None:
-                os.environ["NVW_MODE"] = old
+    e = build_engine(w, B, N, organisation=organisation)
     Lh, sel = device_inputs(B, N, seed)
     e.setInputs(Lh, sel)
     del Lh
     torch.cuda.synchronize()
     e.time_runs(1, min(N, 64), B)
     ms = e.time_runs(1, N, B)
+    info = e.kernelInfo(B, False)
     e.close()
     torch.cuda.empty_cache()
-    return N / ms
+    return N / ms, info
+
+
+def reference_definition_khz(sh, impl, N=16384, chunk=2048):
+    """nv_wavenet_perf.cu:67-87: N samples through run_chunks in chunks of `chunk`, per-chunk copies of the
+    samples into pinned host memory, wall clock around it; kHz per utterance = N / elapsed ms."""
+    import torch
+    w = make_weights(sh, seed=1)
+    e = build_engine(w, sh.B, N, sh=sh, impl=impl)
+    Lh, sel = device_inputs(sh.B, N, 1, sh=sh)
+    e.setInputs(Lh, sel)
+    y = torch.zeros(sh.B, N, dtype=torch.int32).pin_memory()
+    e.run(min(N, 64), sh.B)                    # warm-up (code objects, clocks)
+    e.synchronize()
+    e.setInputs(Lh, sel)
+    del Lh
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ok = e.run_chunks(chunk, None, N, sh.B, y.numpy(), 1)
+    e.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    info = e.kernelInfo(sh.B, False)
+    ok = ok and e.chainStatus() == 0 and int(y.min()) >= 0 and int(y.max()) < sh.A and int(torch.unique(y).numel()) > 8
+    e.close()
+    torch.cuda.empty_cache()
+    return {"khz_per_utterance": (N / ms) if ok else 0.0, "samples_per_sec": (sh.B * N / ms * 1e3) if ok else 0.0,
+            "kernel": info, "samples": N, "chunk": chunk, "batch": sh.B}
+
+
+def end_to_end_khz(w, B, chunk=256, chunks=4, seed=21):
+    """Conditioning streamed per chunk: the fp32 [chunk][L][B][2R] block of chunk j+1 is packed into fragment
+    order on a second stream while chunk j is generated; the samples of every chunk are copied to the host.
+    Returns kHz per utterance over chunks*chunk samples (the first chunk's pack is inside the timed region)."""
+    import torch
+    N = chunk * chunks
+    e = build_engine(w, B, N)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    blocks = [torch.empty(chunk, L, B, 2 * R, dtype=torch.float32, device="cuda").uniform_(-0.25 / R, 0.25 / R, generator=g)
+              for _ in range(2)]                       # two source buffers, refilled round-robin (synthetic)
+    sel = torch.rand(N, B, dtype=torch.float32, device="cuda", generator=g)
+    e.setSelectorSeed(seed)
+    del sel
+    gen, pack = torch.cuda.Stream(), torch.cuda.Stream()
+    y = torch.zeros(B, N, dtype=torch.int32, device="cuda")
+    # warm-up: one chunk through both paths
+    e.packConditioning(blocks[0], 0, chunk, pack.cuda_stream)
+    pack.synchronize()
+    e.run_partial_chunk(0, chunk, N, B, gen.cuda_stream)
+    gen.synchronize()
+    e.resetHistory()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    packed = [torch.cuda.Event() for _ in range(chunks)]
+    done = [torch.cuda.Event() for _ in range(chunks)]
+    e.packConditioning(blocks[0], 0, chunk, pack.cuda_stream)
+    packed[0].record(pack)
+    for j in range(chunks):
+        gen.wait_event(packed[j])
+        e.run_partial_chunk(j * chunk, chunk, N, B, gen.cuda_stream)
+        done[j].record(gen)
+        if j + 1 < chunks:
+            if j >= 1:
+                pack.wait_event(done[j - 1])      # (the source buffer of chunk j+1 was read by the pack of chunk j-1)
+            e.packConditioning(blocks[(j + 1) % 2], (j + 1) * chunk, chunk, pack.cuda_stream)
+            packed[j + 1].record(pack)
+    gen.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    e.getYOut(y, 0, N, None)
+    torch.cuda.synchronize()
+    ok = int(torch.unique(y).numel()) > 8
+    e.close()
+    del blocks
+    torch.cuda.empty_cache()
+    return (N / ms) if ok else 0.0
 
 
 def cpu_run_once(w, n, B=16, seed=5):
@@ -185,6 +279,73 @@ def cpu_baseline(w, budget_s=20.0):
     return out
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: re-execute under torch.distributed.run with N local ranks."""
+    if args.backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) are visible" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def prove_world(dist, world, rank, local_rank, backend):
+    """All ranks exchange (rank, pid, device) through the collective backend: the job really has `world`
+    distinct processes (and, under RCCL, distinct devices).  Returns the gathered table on every rank."""
+    import torch
+    dev = "cuda" if backend == "nccl" else "cpu"
+    mine = torch.tensor([rank, os.getpid(), local_rank], dtype=torch.int64, device=dev)
+    flat = torch.zeros(world * 3, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(flat, mine)
+    table = flat.cpu().reshape(world, 3)
+    ranks = sorted(int(x) for x in table[:, 0])
+    assert ranks == list(range(world)), "rendezvous incomplete: ranks %s of %d" % (ranks, world)
+    assert len(set(int(x) for x in table[:, 1])) == world, "ranks share a process"
+    if backend == "nccl":
+        assert len(set(int(x) for x in table[:, 2])) == world, "ranks share a GPU"
+    return table
+
+
+def selftest_dist(args, world, rank, local_rank):
+    """Launcher / rendezvous / gather plumbing without the engine (no GPU needed): every rank contributes a
+    [b][n] block of its own rank number through nv_wavenet_amd.sharding.gather_samples; prints one JSON line."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend)
+        prove_world(dist, world, rank, local_rank, args.backend)
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nvw_sharding", os.path.join(ROOT, "nv_wavenet_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    b, n = 8, 32
+    y = torch.full((b, n), rank, dtype=torch.int32)
+    full = y
+    if world > 1:
+        full, _ = sharding.gather_samples(y, b * world)
+        dist.barrier()
+    ok = full.shape == (b * world, n) and all(int(full[r * b, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "selftest (launcher + rendezvous + gather, no engine)", "n_gpus": world,
+                          "gathered_rows": int(full.shape[0]), "ok": bool(ok)}))
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,8 +353,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (0 = find the max real-time batch)")
     ap.add_argument("--samples", type=int, default=0, help="samples per step (0 = auto)")
+    ap.add_argument("--config", default="headline", choices=["headline", "c5"],
+                    help="c5: BASELINE configs[4], global batch 64 sharded over the ranks (8 x 8 on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip reference_definition / end_to_end / throughput_mode")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
+    ap.add_argument("--selftest-dist", action="store_true", help="launcher / rendezvous / gather plumbing only (no GPU)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seed", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -202,13 +367,21 @@ def main():
         print(json.dumps({"cpu_worker_seconds": dt}))
         return
 
-    import torch
-    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                      # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.selftest_dist:
+        return selftest_dist(args, world, rank, local_rank)
+
+    import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.backend == "nccl" and torch.cuda.device_count() < world:
+        sys.exit("bench.py: %d ranks but only %d GPU(s) are visible" % (world, torch.cuda.device_count()))
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -217,45 +390,77 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        prove_world(dist, world, rank, local_rank, args.backend)
 
-    from nv_wavenet_amd.sharding import gather_samples
+    from nv_wavenet_amd.sharding import gather_samples, shard_range
     w = make_weights()
     ncu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    extras = world == 1 and not args.no_extras and args.config == "headline"
 
-    # ---- workload: the largest per-GPU batch that stays real time (bounded sweep, rank 0) ----
+    # ---- workload: the largest per-GPU batch that stays real time (bounded bisection, rank 0) ----
     sweep = {}
     c3_b16_khz = None
-    if args.batch:
+    if args.config == "c5":
+        B = shard_range(64, world, rank)[1]          # 8 per GPU on 8 GPUs
+        assert B > 0, "more ranks than utterances"
+    elif args.batch:
         B = args.batch
     else:
         choice = torch.zeros(1, dtype=torch.int64, device="cuda")
         if rank == 0:
-            c3_b16_khz = measure_khz(w, 16, 1024)
+            c3_b16_khz, _ = measure_khz(w, 16, 1024)
             sweep[16] = c3_b16_khz
-            best = 16
-            for tiles_per_cu in (1, 2, 4):
-                cand = 16 * ncu * tiles_per_cu
-                khz = measure_khz(w, cand, 128)
-                sweep[cand] = khz
+            lo, hi = 1, None                      # in tiles of 16 utterances: lo is real time, hi is not
+            for tiles in (ncu, 2 * ncu, 4 * ncu):
+                khz, _ = measure_khz(w, 16 * tiles, 128)
+                sweep[16 * tiles] = khz
                 if khz >= REALTIME_KHZ:
-                    best = cand
+                    lo = tiles
                 else:
+                    hi = tiles
                     break
-            choice[0] = best
+            while hi is not None and hi - lo > 16:  # bisect to 16 tiles (256 utterances)
+                mid = (lo + hi) // 2 // 4 * 4
+                if mid <= lo:
+                    break
+                khz, _ = measure_khz(w, 16 * mid, 128)
+                sweep[16 * mid] = khz
+                if khz >= REALTIME_KHZ:
+                    lo = mid
+                else:
+                    hi = mid
+            choice[0] = 16 * lo
         if world > 1:
             if args.backend != "nccl":
                 choice = choice.cpu()
             dist.broadcast(choice, 0)
         B = int(choice.item())
-    N = args.samples or samples_per_step_for(B)
+    N = args.samples or (2048 if args.config == "c5" else samples_per_step_for(B))
 
-    # throughput mode (not real time): every SIMD owns a tile, weights streamed once per CU
-    thr = None
-    if rank == 0 and not args.batch:
+    # ---- beside the headline (rank 0, one GPU): the reference's own measurement on C2 / C3 / C4, the
+    #      throughput organisation, and the real-time batch with conditioning streamed per chunk ----
+    refdef, thr, e2e = None, None, None
+    if extras and rank == 0:
+        refdef = {}
+        for sh in (C2, C3, C4):
+            refdef[sh.name] = {"single_workgroup": reference_definition_khz(sh, 1),
+                               "multi_cu_chain": reference_definition_khz(sh, 3),
+                               "auto": reference_definition_khz(sh, 0)}
         bt = 64 * ncu
-        khz_t = sweep.get(bt) or measure_khz(w, bt, 128, mode="stream")
+        khz_t, info_t = (sweep.get(bt), None) if sweep.get(bt) else measure_khz(w, bt, 128, organisation=4)
         thr = {"batch_per_gpu": bt, "khz_per_utterance": khz_t, "samples_per_sec_per_gpu": bt * khz_t * 1e3,
                "kernel": "wn::wavenet_stream", "real_time": bool(khz_t >= REALTIME_KHZ)}
+        e2e = {"definition": "conditioning fp32 [N][L][B][2R] in HBM, packed per chunk of 256 samples on a second stream "
+                             "behind the generation of the previous chunk; Philox selectors; samples left in HBM",
+               "sweep_khz": {}}
+        best = None
+        for cand in sorted(set([B // 2, B * 3 // 4, B]), reverse=True):
+            cand = max(16, cand // 64 * 64)
+            k = end_to_end_khz(w, cand)
+            e2e["sweep_khz"][str(cand)] = k
+            if k >= REALTIME_KHZ and best is None:
+                best = cand
+        e2e["max_realtime_batch_per_gpu"] = best
 
     e = build_engine(w, B, N)
     kinfo = e.kernelInfo(B, False)
@@ -266,6 +471,8 @@ def main():
     ybuf = [torch.zeros(B, N, dtype=torch.int32, device="cuda") for _ in range(2)]
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
+    gathered_rows = [0]
+    total_batch = 64 if args.config == "c5" else B * world
 
     pending = []
 
@@ -274,20 +481,20 @@ def main():
         # the gather of step i overlaps the kernel of step i+1 (RCCL runs on its own stream); the gather
         # of step i-2 read the buffer this step overwrites, so it is completed first
         while len(pending) > 1:
-            pending.pop(0)()
+            gathered_rows[0] = pending.pop(0)().shape[0]
         if events is not None:
             events[0].record(stream)
         assert e.run(N, B, y, 1, False, sptr)
         if events is not None:
             events[1].record(stream)
         if world > 1:
-            _, fin = gather_samples(y, B * world, async_op=True)
+            _, fin = gather_samples(y, total_batch, async_op=True)
             pending.append(fin)
 
     for i in range(args.warmup):
         step(i)
     while pending:
-        pending.pop(0)()
+        gathered_rows[0] = pending.pop(0)().shape[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -297,7 +504,7 @@ def main():
     for i in range(args.steps):
         step(i, evs[i])
     while pending:
-        pending.pop(0)()
+        gathered_rows[0] = pending.pop(0)().shape[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -306,24 +513,29 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        assert gathered_rows[0] == total_batch, "the gather returned %d rows, expected %d" % (gathered_rows[0], total_batch)
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
     ylast = ybuf[(args.steps - 1) % 2]
     hist = int(torch.unique(ylast).numel())
+    status = e.chainStatus()
     e.close()
 
     if rank == 0:
+        assert status == 0, "multi-CU hand-off timed out: 0x%x" % status
         ms_per_step = 1e3 * dt / args.steps
-        value = world * B * N / (dt / args.steps)
+        value = total_batch * N / (dt / args.steps)
         khz = N / kern_ms
         units = B * N                                   # utterance-samples per launch
-        flops = units * FLOPS
+        flops = units * HEAD.flops
         tiles = (B + 15) // 16
-        stream_mode = tiles > 2 * ncu                           # engine's choice (nv_wavenet.hpp)
-        bt = 2 if tiles > ncu else 1                            # tiles per workgroup of the latency kernel
+        kname = kinfo.split(" ")[0]                             # what the engine reports it launches
+        stream_mode = "wavenet_stream" in kname
+        chain_mode = "wavenet_chain" in kname
+        bt = 2 if "BT=2" in kname else 1
+        if not args.batch and args.config == "headline" and tiles > ncu and not stream_mode:
+            assert kname == HEADLINE_KERNEL, kinfo          # the launch the parity tests pin
         # workgroups (weight-stream passes) per sample
         passes = (tiles + 3) // 4 if stream_mode else (tiles + bt - 1) // bt
-        kname = kinfo.split(" ")[0]                             # what the engine reports it launches
-        assert ("stream" in kname) == stream_mode and (stream_mode or "BT=%d" % bt in kname), kinfo
         traffic = None
         # HBM bytes per launch from the PMC passes of the latest profiled round (profiles/traffic_rNN.json,
         # written by scripts/make_profiles.sh); only valid for the launch shape it was measured on
@@ -339,27 +551,34 @@ def main():
         roofline = dict(bound="mfma", achieved=flops / (kern_ms * 1e-3) / 1e12, peak=MFMA_F16_PEAK_TFLOPS,
                         unit="TFLOP/s", traffic=traffic, kernel=kname, launch=kinfo,
                         kernel_ms=kern_ms,
-                        hbm=dict(achieved=units * HBM_BYTES / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"),
-                        l2_weight_stream=dict(achieved=passes * N * WEIGHT_BYTES / (kern_ms * 1e-3) / 1e9,
-                                              peak=L2_PEAK_GBS, unit="GB/s"),
-                        lds=dict(achieved=passes * N * lds_bytes_per_sample(stream_mode, 1 if stream_mode else bt) / (kern_ms * 1e-3) / 1e9,
-                                 peak=LDS_PEAK_GBS, unit="GB/s"))
+                        hbm=dict(achieved=units * HEAD.hbm_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"))
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         roofline["hbm"]["frac"] = roofline["hbm"]["achieved"] / HBM_PEAK_GBS
-        roofline["l2_weight_stream"]["frac"] = roofline["l2_weight_stream"]["achieved"] / L2_PEAK_GBS
-        roofline["lds"]["frac"] = roofline["lds"]["achieved"] / LDS_PEAK_GBS
+        if not chain_mode:                                      # (the chain reads no weights after its prologue)
+            roofline["l2_weight_stream"] = dict(achieved=passes * N * HEAD.weight_bytes / (kern_ms * 1e-3) / 1e9,
+                                                peak=L2_PEAK_GBS, unit="GB/s")
+            roofline["l2_weight_stream"]["frac"] = roofline["l2_weight_stream"]["achieved"] / L2_PEAK_GBS
+            roofline["lds"] = dict(achieved=passes * N * lds_bytes_per_sample(stream_mode, 1 if stream_mode else bt) / (kern_ms * 1e-3) / 1e9,
+                                   peak=LDS_PEAK_GBS, unit="GB/s")
+            roofline["lds"]["frac"] = roofline["lds"]["achieved"] / LDS_PEAK_GBS
         out = {
             "metric": "samples/sec (all GPUs) at the max real-time batch @24kHz, R64/S256/A256 20L fp16",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "C3: R=64 S=256 A=256 L=20 maxDilation=512 fp16, autoregressive generation",
-                       "batch_per_gpu": B, "global_batch": B * world, "samples_per_step": N,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.config == "c5" else "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "C3: R=64 S=256 A=256 L=20 maxDilation=512 fp16, autoregressive generation"
+                       if args.config == "headline" else
+                       "C5: C3 shape, global batch 64 sharded over the ranks, RCCL gather of the samples",
+                       "batch_per_gpu": B, "global_batch": total_batch, "samples_per_step": N,
                        "parallelism": "batch-sharded x%d, final RCCL all_gather" % world},
             "samples_per_sec_per_gpu": value / world,
             "khz_per_utterance": khz, "max_realtime_batch_per_gpu": B if khz >= REALTIME_KHZ else None,
-            "realtime_sweep_khz": {str(k): v for k, v in sweep.items()},
+            "max_realtime_batch_definition": "conditioning pre-packed in HBM (setInputs outside the timed region, like the "
+                                             "reference's harness); see end_to_end for conditioning streamed per chunk",
+            "realtime_sweep_khz": {str(k): v for k, v in sorted(sweep.items())},
             "c3_b16": {"khz_per_utterance": c3_b16_khz, "samples_per_sec": None if c3_b16_khz is None else 16e3 * c3_b16_khz},
+            "reference_definition": refdef,
+            "end_to_end": e2e,
             "throughput_mode": thr,
             "distinct_samples_in_last_step": hist,
             "roofline": roofline,

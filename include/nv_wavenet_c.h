@@ -81,6 +81,11 @@ void nvw_pack_conditioning(nvw_engine* e, float* Lh, int first_sample, int count
 /* 0 when every multi-CU (wavenet_chain) launch so far ran to completion, else the code of the first
  * hand-off that timed out; synchronises the device */
 unsigned nvw_chain_status(nvw_engine* e);
+/* Samples [init_sample, init_sample + count) of a num_samples-long utterance, asynchronously on `stream`
+ * (one chunk of run_chunks, for hosts that drive the chunks themselves); nvw_reset_history puts the
+ * sample history back to 128 like nvw_set_inputs does, without touching the conditioning. */
+int nvw_run_range(nvw_engine* e, int init_sample, int count, int num_samples, int batch_size, void* stream);
+void nvw_reset_history(nvw_engine* e, void* stream);
 void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed);
 void nvw_set_audio_out(nvw_engine* e, short* pcm_out);
 /* Introspection: the device code nvw_run(e, n, batch_size, ..., dump_activations, ...) launches, e.g.

@@ -37,6 +37,8 @@ SIGNATURES = {
     "nvw_set_conditioning_n": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_pack_conditioning": (None, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_void_p]),
     "nvw_chain_status": (C.c_uint, [C.c_void_p]),
+    "nvw_run_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "nvw_reset_history": (None, [C.c_void_p, C.c_void_p]),
     "nvw_set_selector_seed": (None, [C.c_void_p, C.c_ulonglong]),
     "nvw_set_audio_out": (None, [C.c_void_p, C.c_void_p]),
     "nvw_kernel_info": (None, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]),

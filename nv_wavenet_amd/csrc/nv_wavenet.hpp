@@ -762,6 +762,20 @@ public:
         return result;
     }
 
+    // Samples [init_sample, init_sample + count) only, asynchronously on `stream` (what run_chunks does per
+    // chunk, for callers that drive the chunks themselves, e.g. with the conditioning streamed in between)
+    bool run_range(int init_sample, int count, int num_samples, int batch_size, hipStream_t stream = 0) {
+        m_num_samples_per_chunk = count;
+        const bool ok = run_partial(init_sample, num_samples, batch_size, NULL, 1, false, stream);
+        m_num_samples_per_chunk = 0;
+        return ok;
+    }
+    // the sample history back to 128 (what setInputs does), asynchronously on `stream`
+    void resetHistory(hipStream_t stream = 0) {
+        hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, stream, m_yInPrev, m_yInCur, m_maxBatch);
+        gpuErrChk(hipGetLastError());
+    }
+
     bool run(int num_samples, int batch_size, int* yOut = NULL, int batch_size_per_block = 1,
              bool dumpActivations = false, hipStream_t stream = 0) {
         m_num_samples_per_chunk = 0;

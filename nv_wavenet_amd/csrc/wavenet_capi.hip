@@ -85,6 +85,10 @@ void nvw_pack_conditioning(nvw_engine* e, float* Lh, int first_sample, int count
     e->packConditioning(Lh, first_sample, count, (hipStream_t)stream);
 }
 unsigned nvw_chain_status(nvw_engine* e) { return e->chainStatus(); }
+int nvw_run_range(nvw_engine* e, int init_sample, int count, int num_samples, int batch_size, void* stream) {
+    return e->run_range(init_sample, count, num_samples, batch_size, (hipStream_t)stream) ? 1 : 0;
+}
+void nvw_reset_history(nvw_engine* e, void* stream) { e->resetHistory((hipStream_t)stream); }
 void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed) { e->setSelectorSeed(seed); }
 void nvw_set_audio_out(nvw_engine* e, short* pcmOut) { e->setAudioOut(pcmOut); }
 void nvw_kernel_info(nvw_engine* e, int batch_size, int dump_activations, char* buf, int buf_size) {

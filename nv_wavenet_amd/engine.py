@@ -123,6 +123,13 @@ class WavenetEngine:
         assert Lh.numel() == count * self.numLayers * self.maxBatch * 2 * self.R
         lib.nvw_pack_conditioning(self._h, addr(Lh), int(firstSample), int(count), stream)
 
+    def run_partial_chunk(self, init_sample, count, num_samples, batch_size, stream=None):
+        """Samples [init_sample, init_sample+count) of a num_samples-long utterance, asynchronously on `stream`."""
+        return bool(lib.nvw_run_range(self._h, int(init_sample), int(count), int(num_samples), int(batch_size), stream))
+
+    def resetHistory(self, stream=None):
+        lib.nvw_reset_history(self._h, stream)
+
     def chainStatus(self):
         """0 when every multi-CU launch ran to completion (synchronises), else the first time-out code."""
         return int(lib.nvw_chain_status(self._h))

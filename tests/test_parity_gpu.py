@@ -233,6 +233,45 @@ def test_fp16_baseline_configs_teacher_forced_and_identical_across_organisations
     assert np.array_equal(y_wg, y_chain), "wavenet_wg and wavenet_chain disagree in fp16"
 
 
+def test_benchmarked_launch_is_the_parity_tested_one():
+    """What bench.py times by default IS pinned: C3 at BASELINE depth and dilation range (R64/S256/A256, 20 layers,
+    maxDilation 512, fp16) at two tiles per CU -- the engine then launches wavenet_wg with two tiles per workgroup,
+    no dump code, non-temporal ring / conditioning traffic.  The big batch repeats 16 utterances (conditioning
+    tiled on the device), N = 640 samples so the d = 512 taps are live and the rings wrap, and must reproduce, bit
+    for bit, the 16-utterance run of the one-tile kernel -- which itself is held to the fp32 oracle teacher-forced
+    (>= 99.5 % of picks identical, every other one a CDF-edge case)."""
+    import torch
+    import bench
+    from nv_wavenet_amd import WavenetEngine
+    case = cases.Case("C3_fp16_benchmarked_launch", 30, [], cases.Shape(64, 256, 256, 20, 16, 640, 512), 3, 1, 128)
+    s = case.shape
+    y16 = _teacher_forced(case, "wg")                   # checks the small run against the oracle
+    t = util.O.gen_test_inputs(case.seed, case.prior, s, "oracle")
+    t.round_to_half()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    B = 2 * 16 * ncu                                    # the batch bench.py settles on (two tiles per CU)
+    e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, B, s.N, impl=0, tanhEmbed=True, precision=16)
+    info = e.kernelInfo(B, False)
+    assert info.split(" ")[0] == bench.HEADLINE_KERNEL, info
+    e.setEmbeddings(t.embP, t.embC)
+    for l in range(s.L):
+        e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
+    e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
+    idx = torch.arange(B, device="cuda") % s.B
+    Lh = torch.from_numpy(t.Lh).cuda()[:, :, idx, :].contiguous()          # [N][L][B][2R]
+    sel = torch.from_numpy(t.sel).cuda()[:, idx].contiguous()             # [N][B]
+    e.setInputs(Lh, sel)
+    del Lh
+    y = torch.full((B, s.N), -1, dtype=torch.int32, device="cuda")
+    assert e.run(s.N, B, y, 1, False)
+    e.synchronize()
+    y = y.cpu().numpy()
+    ref = y16[idx.cpu().numpy()]
+    bad = np.argwhere((y != ref).any(axis=1))
+    assert bad.size == 0, "utterance %d of the benchmarked launch differs from the 16-utterance run" % int(bad[0, 0])
+    e.close()
+
+
 def _wrapper_model(R, S, A, L, B, N, seed=7):
     """export_weights()-shaped random tensors (pytorch/wavenet.py:147-188) + a conditioning tensor."""
     import torch
