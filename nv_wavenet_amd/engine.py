@@ -147,7 +147,7 @@ class WavenetEngine:
         lib.nvw_set_selector_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF)
 
     def setAudioOut(self, pcmOut):
-        """pcmOut: int16 [maxBatch][maxSamples] (numpy or CUDA tensor) filled wherever yOut is with
+        """pcmOut: int16 [batch][num_samples] of the run calls that follow (numpy or CUDA tensor) filled wherever yOut is with
         int16(32768 * mu_law_decode(y, A)); None switches it off."""
         if pcmOut is not None:
             if hasattr(pcmOut, "data_ptr"):
@@ -156,7 +156,7 @@ class WavenetEngine:
             else:
                 assert pcmOut.dtype == np.int16 and pcmOut.flags["C_CONTIGUOUS"]
             n = pcmOut.numel() if hasattr(pcmOut, "numel") else pcmOut.size
-            assert n >= self.maxBatch * self.maxSamples
+            assert n >= self.maxBatch, "pcmOut must hold [batch][num_samples] int16"
         self._pcm_keep = pcmOut
         lib.nvw_set_audio_out(self._h, addr(pcmOut) if pcmOut is not None else None)
 

@@ -146,12 +146,23 @@ class NVWaveNetEngine(NVWaveNet):
             "no engine for R,S,A,precision = %s in this build" % (dims + (self.precision,),)
         return dims
 
+    # engines are kept per (batch, sample CAPACITY, implementation): the capacity is the sample count rounded up
+    # to a bucket, and an utterance shorter than the capacity runs as a prefix (conditioning, selectors and
+    # samples are sample-major), so a new utterance length neither rebuilds the engine nor re-uploads the
+    # weights.  At most MAX_ENGINES stay alive (least recently used goes first).
+    BUCKET = 4096
+    MAX_ENGINES = 4
+
     def _engine(self, batch_size, sample_count, implementation):
         from .engine import WavenetEngine
-        key = (batch_size, sample_count, int(implementation))
-        e = self._engines.get(key)
+        capacity = -(-sample_count // self.BUCKET) * self.BUCKET
+        key = (batch_size, capacity, int(implementation))
+        e = self._engines.pop(key, None)
         if e is None:
-            e = WavenetEngine(self.R, self.S, self.A, self.num_layers, self.max_dilation, batch_size, sample_count,
+            while len(self._engines) >= self.MAX_ENGINES:
+                old_key = next(iter(self._engines))
+                self._engines.pop(old_key).close()
+            e = WavenetEngine(self.R, self.S, self.A, self.num_layers, self.max_dilation, batch_size, capacity,
                               impl=int(implementation), tanhEmbed=bool(self.use_embed_tanh), precision=self.precision)
             f = lambda t: t.float().contiguous()
             e.setEmbeddings(f(self.embedding_prev), f(self.embedding_curr))
@@ -159,7 +170,7 @@ class NVWaveNetEngine(NVWaveNet):
                 e.setLayerWeights(l, *[f(t) for t in self.layers[7 * l:7 * l + 7]])
             zeros = torch.zeros(self.A, dtype=torch.float32, device=self.conv_out.device)
             e.setOutWeights(f(self.conv_out), zeros, f(self.conv_end), zeros)   # wavenet_infer.cu:75-82
-            self._engines[key] = e
+        self._engines[key] = e          # (re-)inserted last: most recently used
         return e
 
     def close(self):
@@ -183,20 +194,26 @@ class NVWaveNetEngine(NVWaveNet):
         sample_count, batch_size = cond_input.size(0), cond_input.size(2)
         cond_input = cond_input.float()
         e = self._engine(batch_size, sample_count, implementation)
+        # everything below is ordered on the caller's current stream: the tensors above were produced on it,
+        # the engine's launches go to it, and the results are consumed on it
+        stream = torch.cuda.current_stream(cond_input.device)
+        sptr = stream.cuda_stream
         if seed is None:
             sel = torch.rand(sample_count, batch_size, dtype=torch.float32, device=cond_input.device,
                              generator=generator)
-            e.setInputs(cond_input, sel)
+            stream.synchronize()        # setInputs packs on the engine's upload stream
+            e.setInputs(cond_input, sel, sample_count)
         else:
-            e.setConditioning(cond_input)
+            stream.synchronize()
+            e.setConditioning(cond_input, sample_count)
             e.setSelectorSeed(seed)
         samples = torch.zeros(batch_size, sample_count, dtype=torch.int32, device=cond_input.device)
         audio = torch.zeros(batch_size, sample_count, dtype=torch.int16, device=cond_input.device) \
             if return_audio else None
         e.setAudioOut(audio)
         bspb = 4 if batch_size % 4 == 0 else 2 if batch_size % 2 == 0 else 1
-        ok = e.run(sample_count, batch_size, samples, bspb, False)
-        e.synchronize()
+        ok = e.run(sample_count, batch_size, samples, bspb, False, sptr)
+        stream.synchronize()
         e.setAudioOut(None)
-        assert ok, "nvWavenetInfer::run failed"
+        assert ok and e.chainStatus() == 0, "nvWavenetInfer::run failed"
         return (samples, audio) if return_audio else samples

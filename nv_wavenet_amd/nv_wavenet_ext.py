@@ -9,11 +9,29 @@ import ctypes as C
 from ._lib import lib, addr
 
 
+def _check(t, name, dtype):
+    have = str(t.dtype).replace("torch.", "")
+    if have != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, have))
+    contiguous = t.is_contiguous() if hasattr(t, "is_contiguous") else t.flags["C_CONTIGUOUS"]
+    if not contiguous:
+        raise ValueError("%s must be contiguous" % name)
+
+
 def infer(samples_tensor, sample_count, batch_size, embed_prev_tensor, embed_curr_tensor, conv_out_tensor,
           conv_end_tensor, cond_input_tensor, num_layers, use_embed_tanh, max_dilation, implementation, layers):
     """layers: flat list, 7 tensors per layer: Wprev, Wcur, Bh, Wres, Bres, Wskip, Bskip
     (wavenet_infer_wrapper.cpp:60-69). Fills samples_tensor [batch][samples] int32; returns 1."""
     assert len(layers) == 7 * num_layers, "expected 7 tensors per layer"
+    # the reference's pybind wrapper reads tensor.data<float>() / data<int>(), which throws on any other dtype;
+    # raw addresses would silently reinterpret a half / double model or an int64 sample buffer
+    _check(samples_tensor, "samples_tensor", "int32")
+    for name, t in (("embed_prev_tensor", embed_prev_tensor), ("embed_curr_tensor", embed_curr_tensor),
+                    ("conv_out_tensor", conv_out_tensor), ("conv_end_tensor", conv_end_tensor),
+                    ("cond_input_tensor", cond_input_tensor)):
+        _check(t, name, "float32")
+    for i, t in enumerate(layers):
+        _check(t, "layers[%d]" % i, "float32")
     ptrs = []
     for k in range(7):
         arr = (C.c_void_p * num_layers)()

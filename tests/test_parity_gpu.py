@@ -348,6 +348,56 @@ def test_wavenet_infer_c_abi_and_python_wrapper():
     o.close()
 
 
+def test_reference_binding_runs_unchanged():
+    """The drop-in claim, proven by running the reference side: the reference's own pybind extension
+    (pytorch/wavenet_infer_wrapper.cpp, compiled by oracle/build_ref_binding.py against libwavenet_infer.so) and its
+    own pytorch/nv_wavenet.py (byte-compiled, unchanged) generate through this engine, and the samples equal both the
+    oracle's (same libc rand() draws) and the ctypes mirror's."""
+    import ctypes
+    import os
+    import sys
+    import importlib.util
+    from importlib.machinery import SourcelessFileLoader
+    import torch
+    from oracle import oracle as O
+    refdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    if not (os.path.exists(os.path.join(refdir, "nv_wavenet_ext.so")) and os.path.exists(os.path.join(refdir, "nv_wavenet_ref.pyc"))):
+        pytest.skip("oracle/_ref binding not built (needs the reference tree at build time)")
+    sys.path.insert(0, refdir)
+    try:
+        import nv_wavenet_ext as ref_ext            # the REFERENCE's extension module
+        loader = SourcelessFileLoader("nv_wavenet_ref", os.path.join(refdir, "nv_wavenet_ref.pyc"))
+        spec = importlib.util.spec_from_loader("nv_wavenet_ref", loader)
+        ref_py = importlib.util.module_from_spec(spec)
+        loader.exec_module(ref_py)                  # the REFERENCE's nv_wavenet.py
+    finally:
+        sys.path.remove(refdir)
+    assert (ref_ext.num_res_channels(), ref_ext.num_skip_channels(), ref_ext.num_out_channels()) == (64, 256, 256)
+    R, S, A, L, B, N, maxD = 64, 256, 256, 6, 3, 24, 4
+    w, dev, cond = _wrapper_model(R, S, A, L, B, N)
+    libc = ctypes.CDLL("libc.so.6")
+    model = ref_py.NVWaveNet(**dev)
+    cond_dev = cond.cuda()
+    model.infer(cond_dev, ref_py.Impl.PERSISTENT)      # warm-up: the HIP runtime draws from rand() when it loads code
+    torch.cuda.synchronize()
+    libc.srand(1234)
+    y = model.infer(cond_dev, ref_py.Impl.PERSISTENT)
+    torch.cuda.synchronize()
+    y = y.cpu().numpy()
+    O._lib("oracle").nvw_srand(1234)
+    sel = np.zeros((N, B), dtype=np.float32)
+    O._lib("oracle").nvw_randomize(sel.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), B, N,
+                                   ctypes.c_float(0.5), ctypes.c_float(1.0))
+    o = _wrapper_oracle(w, cond, R, S, A, L, B, N, maxD, sel)
+    assert np.array_equal(y, o.run(N)), "the reference's binding on this engine disagrees with the oracle"
+    o.close()
+    from nv_wavenet_amd.nv_wavenet import NVWaveNet, Impl
+    mirror = NVWaveNet(**dev)
+    libc.srand(1234)
+    y2 = mirror.infer(cond_dev, Impl.PERSISTENT).cpu().numpy()
+    assert np.array_equal(y, y2)
+
+
 def test_persistent_python_wrapper_seeded_audio():
     """NVWaveNetEngine keeps the engine (and the uploaded weights) alive across
     infer() calls, takes R/S/A from the tensors (here an instantiation wavenet_infer() does not
@@ -372,6 +422,22 @@ def test_persistent_python_wrapper_seeded_audio():
         assert np.array_equal(y.cpu().numpy(), y_ref), "call %d" % call
         assert np.array_equal(audio.cpu().numpy(), table[y_ref])
     assert len(model._engines) == 1, "the engine must be reused across calls"
+    # another utterance LENGTH: same engine (capacity bucket), the shorter conditioning runs as a prefix
+    N2 = 27
+    cond2 = cond[:, :, :, :N2].contiguous()
+    o = _wrapper_oracle(w, cond2, R, S, A, L, B, N2, maxD, util.O.philox_selectors(77, N2, B))
+    y_ref2 = o.run(N2)
+    o.close()
+    y2, audio2 = model.infer(cond2.cuda(), Impl.MANYBLOCK, seed=77, return_audio=True)
+    assert y2.shape == (B, N2) and np.array_equal(y2.cpu().numpy(), y_ref2)
+    assert np.array_equal(audio2.cpu().numpy(), table[y_ref2])
+    assert len(model._engines) == 1, "a new utterance length must not build a new engine"
+    # under a non-default stream the launches follow the caller's stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        y3 = model.infer(cond2.cuda(), Impl.MANYBLOCK, seed=77)
+    side.synchronize()
+    assert np.array_equal(y3.cpu().numpy(), y_ref2)
     # torch-drawn selectors (no seed): plausible output, engine still reused
     y = model.infer(cond_nlbc, Impl.MANYBLOCK, layout="NLBC", generator=torch.Generator(device="cuda").manual_seed(3))
     assert y.shape == (B, N) and int(y.min()) >= 0 and int(y.max()) < A and len(model._engines) == 1
