@@ -295,16 +295,7 @@ WN_DEV bool chain_place(unsigned long long* place, int mine, int consumer, gu32*
     }
 }
 
-// ---- weight fragments pinned in accumulator registers ---------------------------------------------------
-// An empty asm statement whose output is an "a"-class register tied to its input: the value is copied into
-// AGPRs once (4 v_accvgpr_write, in the prologue) and from then on IS an accumulator-file value; the MFMA
-// builtins take it as their A operand in place (v_mfma ... a[n:n+3], v[..], v[..]), with the compiler doing
-// the hazard bookkeeping as for any other operand.
-WN_DEV floatx4 agpr_pin(floatx4 v) {
-    floatx4 o;
-    asm volatile("" : "=a"(o) : "0"(v));
-    return o;
-}
+// ---- weight fragments pinned in accumulator registers: agpr_pin (wn_kernels.hpp) ----------------------------
 
 // acc[mt] += W(tile slot mt) * b  with AGPR-pinned fragments wres[pos0 ...] (the head's resident weights)
 template <bool F16, int MT, int KF, int NFR>

@@ -105,9 +105,11 @@ struct Cfg {
     static constexpr int FW_ZS = ATW * KF_S, FW_ZA = ATW * KF_A;
     static constexpr int FHW = FW_ZS + FW_ZA;
     // depth of the per-wave weight prefetch ring.  Measured on MI355X (C3 fp16, us per sample at
-    // batch 16 / 4096): depth 3: 26.2 / 38.8, 6: 24.5 / 33.3, 9: 22.7 / 29.9, 18: 27.4 / 35.6; a
-    // whole-layer ring refilled at points spread over the layer body instead of at take time: 23.0 /
-    // 28.8 (no better than 9, and it spills with two tiles per workgroup).
+    // batch 16 / 4096): depth 3: 26.2 / 38.8, 6: 24.5 / 33.3, 9: 22.7 / 29.9, 18: 27.4 / 35.6 with the ring in
+    // VGPRs (round 1).  With the ring in the accumulator file (agpr_pin: loads land in AGPRs, the MFMAs read
+    // them in place) depth 9: 19.6 / 24.2 / 33.4 and depth 18 (a whole layer): 21.0 / 26.2 / 37.7 at batch
+    // 16 / 4096 / 8192: a ring that does not divide the streamed head (32 fragments) is rotated once per sample,
+    // and every such rotation -- like every register copy the compiler places on a loop edge -- drains the queue.
 #ifndef WN_PFMAX
 #define WN_PFMAX 12
 #endif
@@ -365,6 +367,27 @@ WN_DEV void lds_get_frags(const char* buf, int lane, typename Prec<F16>::frag (&
     for (int k = 0; k < KF; k++) b[k] = *(const typename Prec<F16>::frag*)(buf + ((k * 64 + lane) << 4));
 }
 
+// ---- values pinned in accumulator registers ---------------------------------------------------------------
+// An empty asm statement whose output is an "a"-class register tied to its input: from there on the value IS
+// an accumulator-file (AGPR) value, and the MFMA builtins take it as their A operand in place
+// (v_mfma ... a[n:n+3], v[..], v[..]) with the compiler doing the hazard bookkeeping as for any operand.
+// Applied to a LOADED value right where it is consumed, the load itself is allocated an AGPR destination
+// (global_load_dwordx4 a[n:n+3], ...) and the wait for it stays a counted s_waitcnt vmcnt(depth-1) in front of
+// the MFMA: the weight prefetch ring then costs no architectural VGPRs at all and can be a whole layer deep.
+// (Left alone, the compiler keeps such values in the VGPR class, spills them to AGPRs under pressure and
+// copies each fragment back with 4 v_accvgpr_read + wait states in front of its MFMA.)
+WN_DEV floatx4 agpr_pin(floatx4 v) {
+    floatx4 o;
+    asm volatile("" : "=a"(o) : "0"(v));
+    return o;
+}
+template <bool F16> WN_DEV typename Prec<F16>::frag agpr_operand(typename Prec<F16>::frag f) {
+    // fp16 builds keep the MFMA accumulators in VGPRs (-amdgpu-mfma-vgpr-form), so the AGPR file is free for
+    // operands; fp32 builds (the parity mode) accumulate in AGPRs and leave the placement to the compiler
+    if constexpr (F16) return __builtin_bit_cast(typename Prec<F16>::frag, agpr_pin(__builtin_bit_cast(floatx4, f)));
+    else return f;
+}
+
 // ------------------------------------------------------------------------------------------
 // weight stream: PF fragments always in flight ahead of the MFMA that consumes them
 // ------------------------------------------------------------------------------------------
@@ -381,7 +404,7 @@ template <bool F16, int PF, int WRAP>
 WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const char* base, const char* wrapBase,
                                      unsigned laneOff, int rtWrapAt = 0x7fffffff, long rtWrapDelta = 0) {
     using frag = typename Prec<F16>::frag;
-    frag a = ws.buf[idx % PF];
+    frag a = agpr_operand<F16>(ws.buf[idx % PF]);   // the ring lives in the accumulator file (see agpr_pin)
     int nidx = idx + PF;
 #ifndef WN_ABL_NOWEIGHTLOAD
     // base / wrapBase are wave-uniform (SGPR base), laneOff = lane*16.  rtWrapAt/rtWrapDelta: a
@@ -462,7 +485,7 @@ WN_DEV void gemm_res(const typename Prec<F16>::frag (&wres)[NFR], int pos0, floa
             for (int mi = 0; mi < G; mi++)
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++)
-                    acc[bt][mg * G + mi] = mma(wres[pos0 + (mg * KF + kf) * G + mi], b[bt][kf], acc[bt][mg * G + mi]);
+                    acc[bt][mg * G + mi] = mma(agpr_operand<F16>(wres[pos0 + (mg * KF + kf) * G + mi]), b[bt][kf], acc[bt][mg * G + mi]);
 }
 
 // ------------------------------------------------------------------------------------------
