@@ -37,6 +37,7 @@
 
 #include "wn_chain.hpp"
 #include "wn_kernels.hpp"
+#include "wn_pipe.hpp"
 #include "wn_stream.hpp"
 
 #ifndef gpuErrChk
@@ -57,7 +58,8 @@ enum nvwOrganisation {
     NVW_ORG_WG2 = 3,      // wn::wavenet_wg, two tiles per workgroup
     NVW_ORG_STREAM = 4,   // wn::wavenet_stream (loader / consumer waves, 4 tiles per workgroup)
     NVW_ORG_CHAIN = 5,    // wn::wavenet_chain, as many layers per CU as stay resident
-    NVW_ORG_CHAIN1 = 6    // wn::wavenet_chain, one layer per CU
+    NVW_ORG_CHAIN1 = 6,   // wn::wavenet_chain, one layer per CU
+    NVW_ORG_PIPE = 7      // wn::wavenet_pipe: the chain kept full (groups of tiles in flight per chain), large batches
 };
 
 template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
@@ -75,6 +77,7 @@ protected:
     using C = wn::Cfg<F16, R, S, A, 1>;   // stream / layout constants do not depend on BT
     using SC = wn::SCfg<F16, R, S, A>;     // throughput (loader/consumer) kernel
     using CC = wn::CCfg<F16, R, S, A>;     // multi-CU chain
+    using PC = wn::PCfg<F16, R, S, A>;     // multi-CU chain kept full (throughput)
     using elem = typename wn::Prec<F16>::elem;
 
     Implementation m_implementation;
@@ -84,6 +87,7 @@ protected:
     bool m_supported;    // false: this shape does not fit the CU (run() returns false, like the reference's unsupported variants)
     int m_streamNS;      // LDS ring slots of the throughput kernel
     int m_chainLpc, m_chainStages;   // layers per chain stage, stages (layer stages + head)
+    int m_pipeChains, m_pipeGroups;  // wavenet_pipe: chains, groups of PC::G tiles per chain (0: not this organisation)
     bool m_tanhEmbed;
     int m_num_samples_per_chunk;
     int m_ringSlots;
@@ -252,12 +256,37 @@ protected:
         if (org == NVW_ORG_STREAM && !streamFits()) org = NVW_ORG_WG;
         if (org == NVW_ORG_CHAIN && !chainFits(chainLpcMax(m_numLayers), tiles)) org = singleOrg(tiles);
         if (org == NVW_ORG_CHAIN1 && !(CC::SUPPORTED && chainFits(1, tiles))) org = singleOrg(tiles);
+        m_pipeChains = m_pipeGroups = 0;
+        if (org == NVW_ORG_PIPE) {
+            if (!pipeGeometry(tiles, m_pipeChains, m_pipeGroups)) {
+                m_pipeChains = m_pipeGroups = 0;
+                org = singleOrg(tiles);
+            }
+        }
         m_org = org;
         m_streamMode = org == NVW_ORG_STREAM;
-        m_chainLpc = org == NVW_ORG_CHAIN ? chainLpcMax(m_numLayers) : org == NVW_ORG_CHAIN1 ? 1 : 0;
+        m_chainLpc = org == NVW_ORG_CHAIN ? chainLpcMax(m_numLayers) : org == NVW_ORG_CHAIN1 ? 1 : org == NVW_ORG_PIPE ? pipeLpc(m_numLayers) : 0;
         m_chainStages = m_chainLpc ? chainStagesFor(m_numLayers, m_chainLpc) : 0;
     }
-    bool isChain() const { return m_chainLpc > 0; }
+    bool isChain() const { return m_chainLpc > 0 && m_pipeGroups == 0; }
+    bool isPipe() const { return m_pipeGroups > 0; }
+    // wavenet_pipe geometry for `tiles` tiles: as many chains as the GPU holds, groups of PC::G tiles per chain
+    static int pipeLpc(int L) {
+        if (!PC::SUPPORTED) return 0;
+        const int ns = (L + PC::LPC - 1) / PC::LPC;
+        return (L + ns - 1) / ns;
+    }
+    bool pipeGeometry(int tiles, int& chains, int& groups) const {
+        const int lpc = pipeLpc(m_numLayers);
+        if (lpc == 0) return false;
+        const int maxChains = m_numCUs / chainStagesFor(m_numLayers, lpc);
+        if (maxChains < 1) return false;
+        const int perChain = (tiles + maxChains - 1) / maxChains;
+        groups = (perChain + PC::G - 1) / PC::G;
+        if (groups > PC::MAX_GROUPS) return false;
+        chains = (tiles + groups * PC::G - 1) / (groups * PC::G);
+        return true;
+    }
     // tiles per workgroup of wn::wavenet_wg for a batch of `tiles` tiles
     int wgTiles(int tiles) const {
         const bool two = m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs);
@@ -290,7 +319,7 @@ public:
         // The bias table of the whole model lives in the LDS of a wavenet_wg workgroup: a model whose
         // table does not fit cannot run there (the reference prints and returns false for shapes a
         // variant does not support, nv_wavenet_singleblock.cuh:273-286)
-        m_supported = isChain() || m_streamMode || ldsFits<1>();
+        m_supported = isChain() || isPipe() || m_streamMode || ldsFits<1>();
         if (!m_supported)
             fprintf(stderr, "nvWavenetInfer: R=%d S=%d A=%d with %d layers needs %zu bytes of LDS (> 160 KiB): unsupported\n", R,
                     S, A, numLayers, ldsNeed<1>(numLayers, 0));
@@ -301,6 +330,7 @@ public:
             const int tiles = (batchSize + 15) / 16;
             const int group = m_streamMode ? 4 : (m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs)) ? 2 : 1;
             m_tiles = (tiles + group - 1) / group * group;
+            if (isPipe()) m_tiles = m_pipeChains * m_pipeGroups * PC::G;
         }
 
         // dilation schedule (nv_wavenet.cuh:99,110-111): d doubles per layer, back to 1 past maxDilation
@@ -354,6 +384,16 @@ public:
 
         gpuErrChk(hipMalloc(&m_chainStatus, 4 * sizeof(unsigned)));
         gpuErrChk(hipMemset(m_chainStatus, 0, 4 * sizeof(unsigned)));
+        if (isPipe()) {
+            m_mailBytes = PC::mailGranules(m_pipeChains, m_chainStages, m_pipeGroups) * sizeof(unsigned long long);
+            gpuErrChk(hipMalloc(&m_mail, m_mailBytes));
+            gpuErrChk(hipMemset(m_mail, 0, m_mailBytes));
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_pipe<F16, R, S, A, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)PC::ldsBytes()));
+            if constexpr (F16)
+                gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_pipe<F16, R, S, A, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)PC::ldsBytes()));
+        }
         if (isChain()) {
             m_mailBytes = CC::mailGranules((batchSize + 15) / 16, m_chainStages) * sizeof(unsigned long long);
             gpuErrChk(hipMalloc(&m_mail, m_mailBytes));
@@ -368,7 +408,7 @@ public:
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
 
-        if (m_supported && !isChain() && !m_streamMode) {
+        if (m_supported && !isChain() && !isPipe() && !m_streamMode) {
             allowLds<1>();
             allowLds<2>();
         }
@@ -581,6 +621,12 @@ public:
     void kernelInfo(int batch_size, bool dumpActivations, char* buf, int n) const {
         const int tiles = (batch_size + 15) / 16;
         const bool dump = F16 ? dumpActivations : true;
+        if (isPipe()) {
+            snprintf(buf, n, "wn::wavenet_pipe<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d groups=%d tiles/group=%d wgs=%d lds=%zu",
+                     F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, m_pipeChains, m_pipeGroups, PC::G,
+                     m_chainStages * m_pipeChains, PC::ldsBytes());
+            return;
+        }
         if (isChain()) {
             snprintf(buf, n, "wn::wavenet_chain<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d wgs=%d lds=%zu",
                      F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, tiles, m_chainStages * tiles,
@@ -674,7 +720,7 @@ public:
         }
         if (!stream) gpuErrChk(hipStreamDestroy(genStream));
         gpuErrChk(hipStreamDestroy(outStream));
-        if (isChain() && chainStatus() != 0) ok = false;   // (everything has completed: the check costs nothing)
+        if ((isChain() || isPipe()) && chainStatus() != 0) ok = false;   // (everything has completed: the check costs nothing)
         return ok;
     }
 
@@ -731,7 +777,9 @@ public:
 
         const int tiles = (batch_size + 15) / 16;
         bool result;
-        if (isChain()) {
+        if (isPipe()) {
+            result = launchPipe(p, tiles, stream);
+        } else if (isChain()) {
             result = launchChain(p, tiles, stream);
         } else if (m_streamMode) {
             bool noDump = false;
@@ -783,6 +831,30 @@ public:
     }
 
 protected:
+    // the chain kept full: one launch, every (chain, stage) workgroup resident at the same time
+    bool launchPipe(wn::Params& p, int tiles, hipStream_t stream) {
+        wn::PipeParams pp;
+        pp.mail = m_mail;
+        pp.status = m_chainStatus;
+        pp.stages = m_chainStages;
+        pp.lpc = m_chainLpc;
+        pp.chains = m_pipeChains;
+        pp.groups = m_pipeGroups;
+        pp.tiles = tiles;
+        p.embLds = PC::embTables();
+        bool dump = true;
+        if constexpr (F16) dump = p.dump != 0;
+        gpuErrChk(hipMemsetAsync(m_mail, 0, m_mailBytes, stream));
+        const int grid = 8 * m_chainStages * ((m_pipeChains + 7) / 8);
+        if (dump) {
+            hipLaunchKernelGGL((wn::wavenet_pipe<F16, R, S, A, true>), dim3(grid), dim3(C::THREADS), PC::ldsBytes(), stream, p, pp);
+        } else {
+            if constexpr (F16)
+                hipLaunchKernelGGL((wn::wavenet_pipe<F16, R, S, A, false>), dim3(grid), dim3(C::THREADS), PC::ldsBytes(), stream, p, pp);
+        }
+        return hipGetLastError() == hipSuccess;
+    }
+
     // the multi-CU chain: every (tile, stage) workgroup must be resident at the same time, so tiles are
     // launched in groups of at most CUs / stages chains; mailboxes are re-zeroed before every launch
     bool launchChain(wn::Params& p, int tiles, hipStream_t stream) {

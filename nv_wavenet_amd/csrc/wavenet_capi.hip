@@ -51,8 +51,8 @@ nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, in
         fprintf(stderr, "nvw_create: implementation %d out of range 0..4\n", implementation);
         return NULL;
     }
-    if (organisation < NVW_ORG_AUTO || organisation > NVW_ORG_CHAIN1) {
-        fprintf(stderr, "nvw_create: organisation %d out of range 0..6\n", organisation);
+    if (organisation < NVW_ORG_AUTO || organisation > NVW_ORG_PIPE) {
+        fprintf(stderr, "nvw_create: organisation %d out of range 0..7\n", organisation);
         return NULL;
     }
     nvw_engine* w = e->make(num_layers, max_dilation, batch_size, num_samples, implementation, tanh_embed, organisation);

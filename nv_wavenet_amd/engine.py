@@ -30,7 +30,8 @@ class Org:
     STREAM = 4      # wn::wavenet_stream (loader / consumer waves)
     CHAIN = 5       # wn::wavenet_chain: multi-CU, weights resident, fewest CUs
     CHAIN1 = 6      # wn::wavenet_chain, one layer per CU
-    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "stream": 4, "chain": 5, "chain1": 6}
+    PIPE = 7        # wn::wavenet_pipe: the chain kept full (throughput, large batches)
+    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "stream": 4, "chain": 5, "chain1": 6, "pipe": 7}
 
 
 def supported_configs():
@@ -62,8 +63,8 @@ class WavenetEngine:
         self.precision = precision
         if isinstance(organisation, str) or organisation is None:
             organisation = Org.BY_NAME[organisation]
-        if organisation not in range(7):
-            raise ValueError("organisation must be 0..6")
+        if organisation not in range(8):
+            raise ValueError("organisation must be 0..7")
         self._h = lib.nvw_create_ex(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
                                     1 if tanhEmbed else 0, organisation)
         if not self._h:

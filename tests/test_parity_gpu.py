@@ -25,7 +25,7 @@ def _bspb(B):
 MODES = ["wg", "wg2", "stream", "chain"]
 ALL_MODES = MODES + ["chain1"]
 KERNEL_OF = {"wg": "wavenet_wg<", "wg2": "wavenet_wg<", "stream": "wavenet_stream<", "chain": "wavenet_chain<",
-             "chain1": "wavenet_chain<"}
+             "chain1": "wavenet_chain<", "pipe": "wavenet_pipe<"}
 
 
 def _check_mode(e, mode, shape):
@@ -231,6 +231,42 @@ def test_fp16_baseline_configs_teacher_forced_and_identical_across_organisations
     y_wg = _teacher_forced(case, "wg")
     y_chain = _teacher_forced(case, "chain", chunk=case.chunk)
     assert np.array_equal(y_wg, y_chain), "wavenet_wg and wavenet_chain disagree in fp16"
+
+
+@pytest.mark.parametrize("B", [16, 21, 100, 1000])
+def test_fp16_pipe_identical_to_single_workgroup(B):
+    """wavenet_pipe (the multi-CU chain kept full: groups of 4 tiles in flight per chain, fp16 only) performs the
+    arithmetic of wavenet_wg in the same order: for batches that make one partly filled group, two tiles, two
+    groups and several chains it must generate, bit for bit, what the one-tile kernel generates for the same
+    utterances (which the oracle checks teacher-forced), in one launch and in chunks."""
+    import torch
+    from nv_wavenet_amd import WavenetEngine
+    case = TF_CASES["C3"]
+    s = case.shape
+    y16 = _teacher_forced(case, "wg")
+    t = util.O.gen_test_inputs(case.seed, case.prior, s, "oracle")
+    t.round_to_half()
+    idx = np.arange(B) % s.B
+    e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, B, s.N, impl=0, tanhEmbed=True, precision=16, organisation=util.MODE_ORG["pipe"])
+    assert "wavenet_pipe<" in e.kernelInfo(B, False), e.kernelInfo(B, False)
+    e.setEmbeddings(t.embP, t.embC)
+    for l in range(s.L):
+        e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
+    e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
+    Lh = np.ascontiguousarray(t.Lh[:, :, idx, :])
+    sel = np.ascontiguousarray(t.sel[:, idx])
+    for chunk in (None, 100):
+        e.setInputs(Lh, sel)
+        y = np.full((B, s.N), -1, dtype=np.int32)
+        if chunk:
+            assert e.run_chunks(chunk, None, s.N, B, y, 1)
+        else:
+            assert e.run(s.N, B, y, 1, False)
+        e.synchronize()
+        assert e.chainStatus() == 0
+        bad = np.argwhere((y != y16[idx]).any(axis=1))
+        assert bad.size == 0, "utterance %d differs (chunk %s)" % (int(bad[0, 0]), chunk)
+    e.close()
 
 
 def test_benchmarked_launch_is_the_parity_tested_one():
