@@ -129,14 +129,18 @@ def samples_per_step_for(B):
     return n
 
 
-def measure_khz(w, B, N, seed=11, organisation=0):
+def measure_khz(w, B, N, seed=11, organisation=0, in_place=False):
     """per-utterance kHz of one launch at batch B with pre-packed conditioning (HIP events on the launch
-    stream).  organisation: 0 = the engine's own choice, else a forced nvwOrganisation."""
+    stream), or with the conditioning read in place from the fp32 tensor (in_place).
+    organisation: 0 = the engine's own choice, else a forced nvwOrganisation."""
     import torch
     e = build_engine(w, B, N, organisation=organisation)
     Lh, sel = device_inputs(B, N, seed)
     e.setInputs(Lh, sel)
-    del Lh
+    if in_place:
+        e.setConditioningDirect(Lh)
+    else:
+        del Lh
     torch.cuda.synchronize()
     e.time_runs(1, min(N, 64), B)
     ms = e.time_runs(1, N, B)
@@ -461,6 +465,12 @@ def main():
             if k >= REALTIME_KHZ and best is None:
                 best = cand
         e2e["max_realtime_batch_per_gpu"] = best
+        # ... and with no pack at all: the kernels read the caller's fp32 tensor in place (setConditioningDirect)
+        k_ip, info_ip = measure_khz(w, B, 128, in_place=True)
+        e2e["in_place"] = {"definition": "conditioning fp32 [N][L][B][2R] in HBM read in place by the generation kernel "
+                                         "(nvw_set_conditioning_direct): no packed copy, no second pass",
+                           "batch_per_gpu": B, "khz_per_utterance": k_ip, "kernel": info_ip.split(" ")[0],
+                           "real_time": bool(k_ip >= REALTIME_KHZ)}
 
     e = build_engine(w, B, N)
     kinfo = e.kernelInfo(B, False)

@@ -78,6 +78,13 @@ void nvw_set_conditioning_n(nvw_engine* e, float* Lh, int num_samples);
  * sample first_sample, device memory) asynchronously on `stream`, e.g. behind nvw_run_partial of the
  * previous chunk on another stream.  Does not touch the sample history. */
 void nvw_pack_conditioning(nvw_engine* e, float* Lh, int first_sample, int count, void* stream);
+/* Device-resident conditioning consumed IN PLACE (no packed copy; pytorch/README.md:44 recommends keeping cond_input on
+ * the device, wavenet_infer.cu:124-143 still copies it): Lh is fp32 [num_samples][L][batch][2R] in device memory, owned by
+ * the caller and kept alive and unchanged until the run calls that follow have completed.  Resets the history like
+ * nvw_set_inputs; pair with nvw_set_selector_seed.  Same samples as the packed path, bit for bit. */
+void nvw_set_conditioning_direct(nvw_engine* e, float* Lh, int num_samples);
+/* the selector half of nvw_set_inputs ([num_samples][batch] uniform draws, host or device); conditioning and history untouched */
+void nvw_set_selectors(nvw_engine* e, float* output_selectors, int num_samples);
 /* 0 when every multi-CU (wavenet_chain) launch so far ran to completion, else the code of the first
  * hand-off that timed out; synchronises the device */
 unsigned nvw_chain_status(nvw_engine* e);

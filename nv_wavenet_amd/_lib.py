@@ -36,6 +36,8 @@ SIGNATURES = {
     "nvw_set_inputs_n": (None, [C.c_void_p, _fp, _fp, C.c_int]),
     "nvw_set_conditioning_n": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_pack_conditioning": (None, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_void_p]),
+    "nvw_set_conditioning_direct": (None, [C.c_void_p, _fp, C.c_int]),
+    "nvw_set_selectors": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_chain_status": (C.c_uint, [C.c_void_p]),
     "nvw_run_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "nvw_reset_history": (None, [C.c_void_p, C.c_void_p]),

@@ -13,6 +13,8 @@ struct nvw_engine {
     virtual void setInputs(float*, float*, int) = 0;
     virtual void setConditioning(float*, int) = 0;
     virtual void packConditioning(float*, int, int, hipStream_t) = 0;
+    virtual void setConditioningDirect(float*, int) = 0;
+    virtual void setSelectors(float*, int) = 0;
     virtual bool run_range(int, int, int, int, hipStream_t) = 0;
     virtual void resetHistory(hipStream_t) = 0;
     virtual bool supported() = 0;
@@ -45,6 +47,8 @@ struct EngineImpl : nvw_engine {
     void setInputs(float* Lh, float* sel, int n) override { eng.setInputs(Lh, sel, n); }
     void setConditioning(float* Lh, int n) override { eng.setConditioning(Lh, n); }
     void packConditioning(float* Lh, int first, int count, hipStream_t s) override { eng.packConditioning(Lh, first, count, s); }
+    void setConditioningDirect(float* Lh, int n) override { eng.setConditioningDirect(Lh, n); }
+    void setSelectors(float* sel, int n) override { eng.setSelectors(sel, n); }
     bool run_range(int i, int c, int n, int b, hipStream_t s) override { return eng.run_range(i, c, n, b, s); }
     void resetHistory(hipStream_t s) override { eng.resetHistory(s); }
     bool supported() override { return eng.supported(); }

@@ -98,6 +98,8 @@ protected:
     elem* m_embedPrev;  // [A][R]
     elem* m_embedCur;
     elem* m_cond;       // packed conditioning
+    int m_condRawSamples;
+    const float* m_condRaw;   // or: the caller's fp32 [N][L][maxBatch][2R] device tensor, consumed in place (setInputsDirect)
     float* m_outputSelectors;
     elem* m_ring;
     int *m_yInPrev, *m_yInCur, *m_yOut;
@@ -180,33 +182,41 @@ protected:
     }
     // DUMP = false (no activation dump code at all) exists for the fp16 engine, the production path;
     // the fp32 engine is the parity mode and always carries the dump
-    template <int BT, bool EMB, bool DUMP> bool launchK(wn::Params& p, int tiles, int nEmb, hipStream_t stream) {
+    template <int BT, bool EMB, bool DUMP, bool RAW> bool launchK(wn::Params& p, int tiles, int nEmb, hipStream_t stream) {
         using CB = wn::Cfg<F16, R, S, A, BT>;
         const int grid = (tiles + BT - 1) / BT;
         p.embLds = nEmb;
-        hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP>), dim3(grid), dim3(CB::THREADS),
+        hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW>), dim3(grid), dim3(CB::THREADS),
                            ldsNeed<BT>(m_numLayers, nEmb), stream, p);
         return hipGetLastError() == hipSuccess;
     }
-    template <int BT> bool launch(wn::Params& p, int tiles, hipStream_t stream) {
+    template <int BT, bool DUMP, bool RAW> bool launchE(wn::Params& p, int tiles, hipStream_t stream) {
         const int nEmb = embTables<BT>();
-        if constexpr (F16) {
-            if (!p.dump) return nEmb ? launchK<BT, true, false>(p, tiles, nEmb, stream) : launchK<BT, false, false>(p, tiles, 0, stream);
-        }
-        return nEmb ? launchK<BT, true, true>(p, tiles, nEmb, stream) : launchK<BT, false, true>(p, tiles, 0, stream);
+        return nEmb ? launchK<BT, true, DUMP, RAW>(p, tiles, nEmb, stream) : launchK<BT, false, DUMP, RAW>(p, tiles, 0, stream);
     }
-    template <int BT, bool EMB, bool DUMP> void allowLdsK() {
+    template <int BT> bool launch(wn::Params& p, int tiles, hipStream_t stream) {
+        const bool raw = p.condRaw != NULL;
+        if constexpr (F16) {
+            if (!p.dump) return raw ? launchE<BT, false, true>(p, tiles, stream) : launchE<BT, false, false>(p, tiles, stream);
+        }
+        return raw ? launchE<BT, true, true>(p, tiles, stream) : launchE<BT, true, false>(p, tiles, stream);
+    }
+    template <int BT, bool EMB, bool DUMP, bool RAW> void allowLdsK() {
         const size_t need = ldsNeed<BT>(m_numLayers, EMB ? embTables<BT>() : 0);
         if (need <= kLdsMax)
-            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP>,
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
     template <int BT> void allowLds() {
-        allowLdsK<BT, false, true>();
-        allowLdsK<BT, true, true>();
+        allowLdsK<BT, false, true, false>();
+        allowLdsK<BT, true, true, false>();
+        allowLdsK<BT, false, true, true>();
+        allowLdsK<BT, true, true, true>();
         if constexpr (F16) {
-            allowLdsK<BT, false, false>();
-            allowLdsK<BT, true, false>();
+            allowLdsK<BT, false, false, false>();
+            allowLdsK<BT, true, false, false>();
+            allowLdsK<BT, false, false, true>();
+            allowLdsK<BT, true, false, true>();
         }
     }
     float* headBias() { return m_bias + (size_t)m_numLayers * C::BIAS_L; }
@@ -298,7 +308,7 @@ public:
                    bool tanhEmbed = true, int organisation = NVW_ORG_AUTO)
         : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
-          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0),
+          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_condRaw(NULL), m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0),
           m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL), m_mulaw(NULL), m_pcmUser(NULL),
           m_stageUsed(0) {
         assert(numLayers >= 2 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
@@ -541,6 +551,7 @@ public:
     void setConditioning(float* Lh) { setConditioning(Lh, m_maxSamples); }
     void setConditioning(float* Lh, int numSamples, hipStream_t stream = 0) {
         assert(numSamples > 0 && numSamples <= m_maxSamples);
+        m_condRaw = NULL;
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, stream, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
         packConditioning(Lh, 0, numSamples, stream);
@@ -579,6 +590,30 @@ public:
                                    dst0 + r0 * dstPerRow, src, nr, m_maxBatch, m_tiles);
             gpuErrChk(hipGetLastError());
         }
+    }
+    // Device-resident conditioning WITHOUT the copy (the reference's own recommendation, README.md:44; SURVEY.md 8f
+    // rank 1): Lh is the caller's fp32 [numSamples][L][maxBatch][2R] tensor in device memory; the kernels read it in
+    // place (16 bytes per lane and gate tile) and nothing is packed.  The caller keeps it alive and unchanged until
+    // the run calls that follow have completed.  Resets the sample history like setInputs.  The loader / consumer
+    // kernel and wavenet_pipe have no in-place path: there (and for host pointers) this is setConditioning.
+    void setConditioningDirect(float* Lh, int numSamples) {
+        assert(numSamples > 0 && numSamples <= m_maxSamples);
+        if (m_streamMode || isPipe() || !isDevicePtr(Lh)) {
+            setConditioning(Lh, numSamples);
+            return;
+        }
+        hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
+        gpuErrChk(hipGetLastError());
+        gpuErrChk(hipStreamSynchronize(0));
+        m_condRaw = Lh;
+        m_condRawSamples = numSamples;
+    }
+    bool conditioningInPlace() const { return m_condRaw != NULL; }
+    // the selector half of setInputs: [numSamples][maxBatch] uniform draws (host or device), conditioning and history untouched
+    void setSelectors(float* outputSelectors, int numSamples) {
+        assert(numSamples > 0 && numSamples <= m_maxSamples);
+        m_useRng = false;
+        gpuErrChk(hipMemcpy(m_outputSelectors, outputSelectors, (size_t)numSamples * m_maxBatch * sizeof(float), hipMemcpyDefault));
     }
     // Selectors are drawn inside the kernel: Philox4x32-10, counter {sample, utterance, 0, 0}, key =
     // seed (replaces the rand() table of pytorch/wavenet_infer.cu:92-94).  A later setInputs()
@@ -743,6 +778,7 @@ public:
         p.embPrev = m_embedPrev;
         p.embCur = m_embedCur;
         p.cond = m_cond;
+        p.condRaw = m_condRaw;
         p.sel = m_outputSelectors;
         p.ring = m_ring;
         p.maxDilation = m_maxDilation;
@@ -758,7 +794,7 @@ public:
         p.batch = batch_size;
         p.maxBatch = m_maxBatch;
         p.numSamples = num_samples;
-        p.condSamples = m_maxSamples;
+        p.condSamples = m_condRaw ? m_condRawSamples : m_maxSamples;
         p.initSample = init_sample;
         p.count = m_num_samples_per_chunk ? m_num_samples_per_chunk : num_samples;
         if (p.initSample + p.count > num_samples) p.count = num_samples - p.initSample;

@@ -84,6 +84,8 @@ void nvw_set_conditioning_n(nvw_engine* e, float* Lh, int num_samples) { e->setC
 void nvw_pack_conditioning(nvw_engine* e, float* Lh, int first_sample, int count, void* stream) {
     e->packConditioning(Lh, first_sample, count, (hipStream_t)stream);
 }
+void nvw_set_conditioning_direct(nvw_engine* e, float* Lh, int num_samples) { e->setConditioningDirect(Lh, num_samples); }
+void nvw_set_selectors(nvw_engine* e, float* sel, int num_samples) { e->setSelectors(sel, num_samples); }
 unsigned nvw_chain_status(nvw_engine* e) { return e->chainStatus(); }
 int nvw_run_range(nvw_engine* e, int init_sample, int count, int num_samples, int batch_size, void* stream) {
     return e->run_range(init_sample, count, num_samples, batch_size, (hipStream_t)stream) ? 1 : 0;

@@ -455,8 +455,20 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
                 const int l = l0 + li;
                 const float* bl = biasLds + li * 3 * R;
                 const char* cp0 = condMine + ((size_t)t * L + l) * condStride;
+                if (p.condRaw) {
+                    // the caller's fp32 [sample][L][maxBatch][2R] tensor read in place: 4 channels of this lane's utterance
+                    // per gate tile, scaled and rounded like pack_cond_tiled_kernel would have (bit-identical to packed runs)
+                    const float* rb = p.condRaw + (((size_t)t * L + l) * p.maxBatch + ub) * (2 * R) + g * 4;
+                    frag raw[(F16 ? 2 : 1) * C::COND_FR];
 #pragma unroll
-                for (int k = 0; k < C::COND_FR; k++) cd[0][k] = *(const frag*)(cp0 + k * 1024 + laneOff);
+                    for (int it = 0; it < 2 * HTW; it++)
+                        raw[it] = __builtin_bit_cast(frag, *(const floatx4*)(rb + (w + NW * (it >> 1) + (it & 1) * RT) * 16));
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++) cd[0][k] = cond_frag<F16, true>(raw, k);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++) cd[0][k] = *(const frag*)(cp0 + k * 1024 + laneOff);
+                }
 #pragma unroll
                 for (int i = 0; i < HTW; i++) {
                     acc[li][2 * i] = *(const floatx4*)(bl + (w + NW * i) * 16 + g * 4);

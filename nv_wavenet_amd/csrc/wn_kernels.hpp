@@ -197,6 +197,7 @@ struct Params {
     const void* embPrev;     // [A][R] T_data
     const void* embCur;      // [A][R] T_data
     const void* cond;        // [sample][L][tile][wave][COND_FR] fragments
+    const float* condRaw;    // or (RAW kernels) the caller's fp32 [sample][L][maxBatch][2R] tensor, read in place
     const float* sel;        // [N][maxBatch] uniform draws
     void* ring;              // [tile][ringSlots][KF_R] fragments
     int maxDilation;         // dilation doubles per layer and restarts at 1 past this (nv_wavenet.cuh:110-111)
@@ -575,6 +576,24 @@ WN_DEV int softmax_pick(const float* lrow, int sq, int lane, float sel, float (&
     return pick;
 }
 
+// conditioning fragment k of a tile from its registers: the packed fragment itself, or (fp16 engine reading the
+// caller's fp32 tensor in place) built from the two fp32 quads of the gate pair -- scaled by the gate's pre-scale and
+// rounded to fp16 exactly like pack_cond_tiled_kernel does
+template <bool F16, bool RAW, int CR> WN_DEV typename Prec<F16>::frag cond_frag(const typename Prec<F16>::frag (&c)[CR], int k) {
+    if constexpr (RAW && F16) {
+        const floatx4 a = __builtin_bit_cast(floatx4, c[2 * k]), b = __builtin_bit_cast(floatx4, c[2 * k + 1]);
+        half8 f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            f[r] = (_Float16)(a[r] * gate_prescale<true>(false));
+            f[4 + r] = (_Float16)(b[r] * gate_prescale<true>(true));
+        }
+        return f;
+    } else {
+        return c[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // the engine kernel: one workgroup generates `count` samples for BT tiles of 16 utterances
 // ------------------------------------------------------------------------------------------
@@ -584,7 +603,10 @@ WN_DEV int softmax_pick(const float* lrow, int sq, int lane, float sel, float (&
 // DUMP: the variant that can write the activation dump of the launch's last sample (getXtOut ...).
 // Production launches (dumpActivations = false) use DUMP = false: even as a never-taken branch the
 // dump costs accumulator read-outs in every layer (35.6 vs 39.0 us per sample at batch 8192).
-template <bool F16, int R, int S, int A, int BT, bool EMBLDS, bool DUMP = true>
+// RAW: the conditioning is read in place from the caller's fp32 [N][L][B][2R] tensor (Params::condRaw: no packed copy
+// exists); each lane loads the 4 consecutive channels of its utterance per gate tile (16 bytes) and, in the fp16 engine,
+// scales and rounds them exactly as pack_cond_tiled_kernel would have, so packed and in-place runs are bit-identical.
+template <bool F16, int R, int S, int A, int BT, bool EMBLDS, bool DUMP = true, bool RAW = false>
 __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_wg(const Params p) {
     using C = Cfg<F16, R, S, A, BT>;
     using P = Prec<F16>;
@@ -698,7 +720,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     // Two register sets used alternately by layer parity (no rotation copies: a copy would force
     // the load issued one layer earlier to have landed, i.e. halve the prefetch distance).
     frag xpA[BT][XPW], xpB[BT][XPW];            // layers of even / odd parity
-    frag cdA[BT][C::COND_FR], cdB[BT][C::COND_FR];
+    // conditioning registers per tile: COND_FR packed fragments, or (fp16, in-place) one fp32 quad per gate tile
+    constexpr int CR = (RAW && F16) ? 2 * C::COND_FR : C::COND_FR;
+    frag cdA[BT][CR], cdB[BT][CR];
     // per-(sample,layer) strides in bytes; everything here is wave-uniform (SALU)
     const size_t condStride = (size_t)p.tiles * NW * C::COND_FR * 1024;            // one (sample,layer) row
     const char* const condMine = (const char*)p.cond + ((size_t)tile0 * NW + w) * C::COND_FR * 1024;
@@ -706,7 +730,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     char* const ringMine = (char*)p.ring + (size_t)tile0 * ringTile;
     // loads (sample tn, layer ln) into (xd, cdd); ln may run past L-1 into the next sample.
     // The conditioning buffer carries one padding sample, so (tEnd, 0..1) stays in bounds.
-    auto prefetch = [&](int tn, int ln, Dil dl, frag (&xd)[BT][XPW], frag (&cdd)[BT][C::COND_FR]) {
+    auto prefetch = [&](int tn, int ln, Dil dl, frag (&xd)[BT][XPW], frag (&cdd)[BT][CR]) {
         if (ln >= L) { ln -= L; tn += 1; }
         const unsigned slot = (unsigned)(dl.off + (tn & (dl.d - 1)));
         const char* rp0 = ringMine + (size_t)slot * (KF_R * 1024);
@@ -727,9 +751,20 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 for (int e = 0; e < P::EPL; e++) xd[bt][i][e] = (elem)(float)(tn + i);
 #endif
 #ifndef WN_ABL_NOCOND
+            if constexpr (RAW) {
+                // gate slot it = 0 .. 2*HTW-1 -> tile w + NW*(it>>1) (+RT for the sigmoid half): 4 channels of this lane's utterance
+                const int tc = tn < p.condSamples ? tn : p.condSamples - 1;      // (the read-ahead past the last sample is never used)
+                const float* rb = p.condRaw + (((size_t)tc * L + ln) * p.maxBatch + ub[bt]) * (2 * R) + g * 4;
 #pragma unroll
-            for (int k = 0; k < C::COND_FR; k++)
-                cdd[bt][k] = ld_stream((const frag*)(cp0 + (size_t)bt * NW * C::COND_FR * 1024 + k * 1024 + laneOff), nt);
+                for (int it = 0; it < 2 * HTW; it++) {
+                    const floatx4 q = ld_stream((const floatx4*)(rb + (w + NW * (it >> 1) + (it & 1) * RT) * 16), nt);
+                    cdd[bt][it] = __builtin_bit_cast(frag, q);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < C::COND_FR; k++)
+                    cdd[bt][k] = ld_stream((const frag*)(cp0 + (size_t)bt * NW * C::COND_FR * 1024 + k * 1024 + laneOff), nt);
+            }
 #else
 #pragma unroll
             for (int k = 0; k < C::COND_FR; k++)
@@ -831,7 +866,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         // its dilated tap was published at the end of the previous layer, and the prefetch for layer
         // l+2 refills it; xpN: the other set, holding the tap of layer l+1 (published at the end).
         auto layer = [&](auto withSkip, const int l, const Dil dl, const Dil dl2, frag (&xpC)[BT][XPW],
-                         frag (&cdC)[BT][C::COND_FR], const frag (&xpN)[BT][XPW]) {
+                         frag (&cdC)[BT][CR], const frag (&xpN)[BT][XPW]) {
             constexpr bool SKIP = decltype(withSkip)::value;
             // fragment positions are relative to the start of layer l-1 (SKIP) / layer l
             const char* wl = wbase + (size_t)(SKIP ? l - 1 : l) * FLW * 1024;
@@ -867,7 +902,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     for (int k = 0; k < C::COND_FR; k++)
 #pragma unroll
                         for (int tt = 0; tt < P::TPF; tt++)
-                            acc[bt][k * P::TPF + tt] = mma(selA[tt], cdC[bt][k], acc[bt][k * P::TPF + tt]);
+                            acc[bt][k * P::TPF + tt] = mma(selA[tt], cond_frag<F16, RAW>(cdC[bt], k), acc[bt][k * P::TPF + tt]);
             } else {
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++)
@@ -1009,7 +1044,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         xpB[bt][i] = tmp;
                     }
 #pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++) {
+                    for (int k = 0; k < CR; k++) {
                         const frag tmp = cdA[bt][k];
                         cdA[bt][k] = cdB[bt][k];
                         cdB[bt][k] = tmp;

@@ -116,6 +116,24 @@ class WavenetEngine:
         assert (Lh.numel() if hasattr(Lh, "numel") else Lh.size) == n, "Lh has the wrong size"
         lib.nvw_set_conditioning_n(self._h, addr(Lh), ns)
 
+    def setConditioningDirect(self, Lh, numSamples=None):
+        """Device-resident conditioning consumed in place: Lh is a CUDA fp32 tensor [numSamples][L][maxBatch][2R]; no
+        packed copy is made and the kernels read it directly.  The tensor is kept referenced here until the next
+        set* call; do not modify it while runs are in flight."""
+        Lh = _f32(Lh)
+        assert hasattr(Lh, "data_ptr") and Lh.is_cuda, "setConditioningDirect takes device tensors"
+        ns = self.maxSamples if numSamples is None else int(numSamples)
+        assert Lh.numel() == ns * self.numLayers * self.maxBatch * 2 * self.R, "Lh has the wrong size"
+        self._cond_keep = Lh
+        lib.nvw_set_conditioning_direct(self._h, addr(Lh), ns)
+
+    def setSelectors(self, outputSelectors, numSamples=None):
+        """The selector half of setInputs: [numSamples][maxBatch] uniform draws; conditioning and history untouched."""
+        sel = _f32(outputSelectors)
+        ns = self.maxSamples if numSamples is None else int(numSamples)
+        assert (sel.numel() if hasattr(sel, "numel") else sel.size) == ns * self.maxBatch
+        lib.nvw_set_selectors(self._h, addr(sel), ns)
+
     def packConditioning(self, Lh, firstSample, count, stream=None):
         """Conditioning streamed chunk by chunk: Lh [count][L][maxBatch][2R] fp32 ON THE DEVICE holds samples
         firstSample .. firstSample+count-1; packed asynchronously on `stream` (history untouched)."""

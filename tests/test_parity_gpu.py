@@ -128,7 +128,7 @@ def test_run_equals_run_chunks_and_partial_batch():
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["R64S256A256_impl3", "R64S128A256_impl1", "R32S128A256_impl1", "R128S256A256_impl3",
                                   "R64S128A512_impl3", "R128S256A1024_impl3", "R256S256A256_L6_B5",
-                                  "R64S128A256_L7_B19_oddL", "R64S256A256_L3_B16_oddL"])
+                                  "R64S128A256_L7_B19_oddL", "R64S256A256_L3_B16_oddL", "R32S256A256_L6_B5_S8R"])
 def test_fp16_engine_against_fp32_oracle(name, mode):
     """fp16 parity is unpinned by the reference (no test runs half). Stated tolerance: with every
     weight / bias / embedding / conditioning value rounded to fp16 and fed to BOTH sides, the fp16
@@ -266,6 +266,61 @@ def test_fp16_pipe_identical_to_single_workgroup(B):
         assert e.chainStatus() == 0
         bad = np.argwhere((y != y16[idx]).any(axis=1))
         assert bad.size == 0, "utterance %d differs (chunk %s)" % (int(bad[0, 0]), chunk)
+    e.close()
+
+
+@pytest.mark.parametrize("precision", [32, 16])
+@pytest.mark.parametrize("mode", ["wg", "wg2", "chain"])
+def test_conditioning_consumed_in_place(mode, precision):
+    """SURVEY.md 8f rank 1 / pytorch/README.md:44: device-resident conditioning WITHOUT the copy.  setConditioningDirect
+    hands the engine the caller's fp32 [N][L][B][2R] device tensor; the kernels read it in place (no packed copy exists)
+    and must generate exactly the samples of the packed path -- fp32 against the oracle as well, ragged batch (21
+    utterances), in one launch and in chunks (the second chunk starts reading mid-tensor)."""
+    import torch
+    case = cases.BY_NAME["C3_R64S256A256_L20_B21"]
+    s = case.shape
+    t = util.gen_inputs(case, half=(precision == 16))
+    # the parity recipe's magnitudes leave the picks almost independent of the conditioning (logits ~1e-3): scale the
+    # conditioning and the output layers up until the samples demonstrably depend on it
+    t.Lh *= 150.0
+    t.Wskip *= 20.0
+    t.Wzs *= 20.0
+    t.Wza *= 20.0
+    if precision == 16:
+        t.round_to_half()
+    o = util.make_oracle(case, t)
+    y_ref = o.run(s.N)
+    o.set_inputs(np.ascontiguousarray(-t.Lh), t.sel)
+    assert (o.run(s.N) != y_ref).mean() > 0.05, "the test inputs must make the samples depend on the conditioning"
+    o.close()
+    e = util.make_engine(case, t, precision=precision, mode=mode)        # packed: setInputs copies and packs
+    y_packed = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, s.B, y_packed, 1, False)
+    e.synchronize()
+    if precision == 32:
+        assert np.array_equal(y_packed, y_ref)
+    Lh = torch.from_numpy(t.Lh).cuda()
+    before = Lh.clone()
+    for chunk in (None, 16):
+        e.setInputs(t.Lh, t.sel)                 # (selectors; the packed conditioning it leaves behind must NOT be used)
+        e.setConditioningDirect(Lh)
+        y = np.full((s.B, s.N), -1, dtype=np.int32)
+        if chunk:
+            assert e.run_chunks(chunk, None, s.N, s.B, y, 1)
+        else:
+            assert e.run(s.N, s.B, y, 1, False)
+        e.synchronize()
+        assert e.chainStatus() == 0
+        assert np.array_equal(y, y_packed), "in-place conditioning differs from the packed path (chunk %s)" % chunk
+    assert torch.equal(Lh, before), "the caller's tensor was modified"
+    # and the packed copy really is not what is read: scribble over the caller's tensor -> different samples
+    Lh.neg_()
+    e.setInputs(t.Lh, t.sel)
+    e.setConditioningDirect(Lh)
+    y2 = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, s.B, y2, 1, False)
+    e.synchronize()
+    assert not np.array_equal(y2, y_packed)
     e.close()
 
 
