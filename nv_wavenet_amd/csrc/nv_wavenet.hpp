@@ -525,8 +525,8 @@ public:
             packWeightStream(sh + SC::H_ZS, Wzs, A, S, 0);
             packWeightStream(sh + SC::H_ZA, Wza, A, A, 1);   // lane-contiguous logit rows
         } else {
-            packWeight(hf, Wzs, A, S, 0);
-            packWeight(hf + C::FW_ZS, Wza, A, A, 0);
+            packWeight(hf + C::O_ZS, Wzs, A, S, 0);
+            packWeight(hf + C::O_ZA, Wza, A, A, 0);
         }
         gpuErrChk(hipMemcpyAsync(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault, 0));
         gpuErrChk(hipMemcpyAsync(headBias() + A, Bza, A * sizeof(float), hipMemcpyDefault, 0));

@@ -633,6 +633,7 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
     constexpr int HTW = C::HTW, STW = C::STW, ATW = C::ATW;
     constexpr int KF_S = C::KF_S, KF_A = C::KF_A;
     constexpr int HR = CC::HR, HS = CC::HS;
+    constexpr int HSP = HS == 0 ? 0 : (HS == C::FW_ZS ? C::FW_ZS + C::PAD1 : C::FHWP);   // physical length of the streamed part (wn_kernels.hpp: zs | PAD1 | za | PAD2)
 
     char* const skbuf = lds + CC::OFF_HSK;
     char* const zsbuf = lds + CC::OFF_HZS;
@@ -702,11 +703,11 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
     if constexpr (HR > 0) {
 #pragma unroll
         for (int i = 0; i < HR; i++)
-            hw[i] = agpr_pin(__builtin_bit_cast(floatx4, *(const frag*)(whead + (size_t)(HS + i) * 1024 + laneOff)));
+            hw[i] = agpr_pin(__builtin_bit_cast(floatx4, *(const frag*)(whead + (size_t)C::headFrag(HS + i) * 1024 + laneOff)));
     }
     WStream<F16, PF> ws;
     if constexpr (HS > 0) {
-        static_assert(HS >= PF, "streamed head shorter than the prefetch ring");
+        static_assert(HSP >= PF, "streamed head shorter than the prefetch ring");
 #pragma unroll
         for (int i = 0; i < PF; i++) ws.buf[i] = *(const frag*)(whead + (size_t)i * 1024 + laneOff);
     }
@@ -771,7 +772,11 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
 #pragma unroll
             for (int i = 0; i < ATW; i++) zs[0][i] = *(const floatx4*)(headBias + (w + NW * i) * 16 + g * 4);
             if constexpr (HS == 0) gemm_pinned<F16, ATW, KF_S>(hw, 0, zs[0], sbf[0]);
-            else gemm<F16, PF, HS, 1, ATW, KF_S>(ws, 0, whead, whead, laneOff, zs, sbf);
+            else {
+                gemm<F16, PF, HSP, 1, ATW, KF_S>(ws, C::O_ZS, whead, whead, laneOff, zs, sbf);
+#pragma unroll
+                for (int i = 0; i < C::PAD1; i++) (void)take<F16, PF, HSP>(ws, C::FW_ZS + i, whead, whead, laneOff);
+            }
         }
 #pragma unroll
         for (int i = 0; i < ATW; i++) {
@@ -787,12 +792,12 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
             for (int i = 0; i < ATW; i++) za[0][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
             if constexpr (C::ZA_B_FROM_LDS) {
                 static_assert(HR == 0, "the LDS-streamed head is for the large, non-resident heads");
-                gemm_ldsb<F16, PF, HS, 1, ATW, KF_A>(ws, C::FW_ZS, whead, whead, laneOff, za, zsbuf, lane);
+                gemm_ldsb<F16, PF, HSP, 1, ATW, KF_A>(ws, C::O_ZA, whead, whead, laneOff, za, zsbuf, lane);
             } else {
                 frag zb[1][KF_A];
                 lds_get_frags<F16, KF_A>(zsbuf, lane, zb[0]);
                 if constexpr (HR >= C::FW_ZA) gemm_pinned<F16, ATW, KF_A>(hw, C::FW_ZS - HS, za[0], zb[0]);
-                else gemm<F16, PF, HS, 1, ATW, KF_A>(ws, C::FW_ZS, whead, whead, laneOff, za, zb);
+                else gemm<F16, PF, HSP, 1, ATW, KF_A>(ws, C::O_ZA, whead, whead, laneOff, za, zb);
             }
             if constexpr (C::ALIAS_LG) wg_barrier();   // every wave is done with the zs image
 #pragma unroll
@@ -801,13 +806,9 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
                 if (dumpNow && uvalid) *(floatx4*)(p.za + (size_t)ub * A + (w + NW * i) * 16 + g * 4) = za[0][i];
             }
         }
-        // the streamed part of the head is not a multiple of the ring: rotate the ring back into phase
-        if constexpr (HS > 0 && HS % PF != 0) {
-            frag tmp[PF];
+        if constexpr (HS == C::FHW) {
 #pragma unroll
-            for (int i = 0; i < PF; i++) tmp[i] = ws.buf[(i + HS) % PF];
-#pragma unroll
-            for (int i = 0; i < PF; i++) ws.buf[i] = tmp[i];
+            for (int i = 0; i < C::PAD2; i++) (void)take<F16, PF, HSP>(ws, C::O_ZA + C::FW_ZA + i, whead, whead, laneOff);
         }
         wg_barrier();
         WN_CT(2)

@@ -137,6 +137,17 @@ struct Cfg {
 #endif
     static constexpr int HS = FHW - HR;
     static constexpr bool HEADRES = HS == 0;              // the stream cycles over the layers only
+    // The head's part of a wave's stream is laid out  zs | PAD1 | za | PAD2  with zero fragments that bring each matrix
+    // to a whole number of ring turns: however much of the head is streamed (nothing, zs, or zs and za), the ring comes
+    // back in phase for the next sample by itself.  (Without them the ring had to be rotated through registers once
+    // per sample, which needs every load in flight to have landed: a full drain of the prefetch queue.)
+    static constexpr int PAD1 = (PF - FW_ZS % PF) % PF, PAD2 = (PF - FW_ZA % PF) % PF;
+    static constexpr int O_ZS = 0, O_ZA = FW_ZS + PAD1;   // physical fragment offsets inside the head part
+    static constexpr int FHWP = O_ZA + FW_ZA + PAD2;      // physical length of the head part
+    static constexpr int HSP = HS == 0 ? 0 : (HS == FW_ZS ? FW_ZS + PAD1 : FHWP);   // physical length of what is streamed
+    static_assert(HS == 0 || HS == FW_ZS || HS == FHW, "the streamed part of the head is nothing, zs, or all of it");
+    // logical head fragment q (zs then za) -> physical offset
+    __host__ __device__ static constexpr int headFrag(int q) { return q < FW_ZS ? q : q + PAD1; }
     static constexpr int FRAG_ELEMS = 64 * EPL;
     static constexpr int BIAS_L = 3 * R + S;               // fp32 biases per layer: Bh | Bres | Bskip
     static constexpr int COND_FR = 2 * HTW / TPF;          // conditioning fragments per (sample,layer,tile,wave)
@@ -170,7 +181,7 @@ struct Cfg {
     }
     // per-wave stream in memory: [L][FLW] layers | [FHW] head
     __host__ __device__ static size_t headOffsetFrags(int L) { return (size_t)L * FLW; }
-    __host__ __device__ static size_t waveStreamFrags(int L) { return (size_t)L * FLW + FHW; }
+    __host__ __device__ static size_t waveStreamFrags(int L) { return (size_t)L * FLW + FHWP; }
 };
 
 constexpr int kMaxLayers = 128;
@@ -709,7 +720,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     frag hw[HR ? HR : 1];
     if constexpr (HR > 0) {
 #pragma unroll
-        for (int i = 0; i < HR; i++) hw[i] = *(const frag*)(whead + (size_t)(HS + i) * 1024 + laneOff);
+        for (int i = 0; i < HR; i++) hw[i] = *(const frag*)(whead + (size_t)C::headFrag(HS + i) * 1024 + laneOff);
     }
 
     // ---- prefetch of the dilated input + conditioning, TWO layers ahead (HBM latency of the
@@ -1080,7 +1091,11 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 for (int i = 0; i < ATW; i++) zs[bt][i] = *(const floatx4*)(headBias + (w + NW * i) * 16 + g * 4);
             }
             if constexpr (HS == 0) gemm_res<F16, BT, ATW, KF_S>(hw, 0, zs, sb);
-            else gemm<F16, PF, HS, BT, ATW, KF_S>(ws, 0, whead, wbase, laneOff, zs, sb);
+            else {
+                gemm<F16, PF, C::HSP, BT, ATW, KF_S>(ws, C::O_ZS, whead, wbase, laneOff, zs, sb);
+#pragma unroll
+                for (int i = 0; i < C::PAD1; i++) (void)take<F16, PF, C::HSP>(ws, C::FW_ZS + i, whead, wbase, laneOff);   // (zero fragments)
+            }
         }
 #pragma unroll
         for (int bt = 0; bt < BT; bt++)
@@ -1102,13 +1117,13 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     za[bt][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
             if constexpr (C::ZA_B_FROM_LDS) {
                 static_assert(HR == 0, "the LDS-streamed head is for the large, non-resident heads");
-                gemm_ldsb<F16, PF, HS, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zsbuf, lane);
+                gemm_ldsb<F16, PF, C::HSP, BT, ATW, KF_A>(ws, C::O_ZA, whead, wbase, laneOff, za, zsbuf, lane);
             } else {
                 frag zb[BT][KF_A];
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_A>(zsbuf + bt * KF_A * 1024, lane, zb[bt]);
                 if constexpr (HR >= C::FW_ZA) gemm_res<F16, BT, ATW, KF_A>(hw, C::FW_ZS - HS, za, zb);
-                else gemm<F16, PF, HS, BT, ATW, KF_A>(ws, C::FW_ZS, whead, wbase, laneOff, za, zb);
+                else gemm<F16, PF, C::HSP, BT, ATW, KF_A>(ws, C::O_ZA, whead, wbase, laneOff, za, zb);
             }
             if constexpr (C::ALIAS_LG) wg_barrier();   // every wave is done with the zs image
             // logits -> LDS [utt][row] (row stride padded by 4 floats: conflict-free b128 writes)
@@ -1122,13 +1137,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 }
         }
         WN_TMARK(8)
-        // the head is not a multiple of the ring: rotate the ring back into phase
-        if constexpr (HS > 0 && HS % PF != 0) {
-            frag tmp[PF];
+        if constexpr (HS == FHW) {
 #pragma unroll
-            for (int i = 0; i < PF; i++) tmp[i] = ws.buf[(i + HS) % PF];
-#pragma unroll
-            for (int i = 0; i < PF; i++) ws.buf[i] = tmp[i];
+            for (int i = 0; i < C::PAD2; i++) (void)take<F16, PF, C::HSP>(ws, C::O_ZA + C::FW_ZA + i, whead, wbase, laneOff);   // (zero fragments)
         }
         wg_barrier();
         WN_TMARK(9)

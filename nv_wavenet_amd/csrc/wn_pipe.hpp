@@ -534,7 +534,7 @@ WN_DEV void pipe_head(const Params& p, const PipeParams& pp, char* lds, int chai
     const char* const whead = (const char*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 1024 + C::headOffsetFrags(L) * 1024;
     floatx4 hw[FHW];
 #pragma unroll
-    for (int i = 0; i < FHW; i++) hw[i] = agpr_pin(__builtin_bit_cast(floatx4, *(const frag*)(whead + (size_t)i * 1024 + laneOff)));
+    for (int i = 0; i < FHW; i++) hw[i] = agpr_pin(__builtin_bit_cast(floatx4, *(const frag*)(whead + (size_t)C::headFrag(i) * 1024 + laneOff)));
     __syncthreads();
 
     for (int i = tid; i < pp.groups * G * 16; i += C::THREADS) {

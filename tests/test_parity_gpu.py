@@ -233,6 +233,38 @@ def test_fp16_baseline_configs_teacher_forced_and_identical_across_organisations
     assert np.array_equal(y_wg, y_chain), "wavenet_wg and wavenet_chain disagree in fp16"
 
 
+def test_chain_fills_the_gpu_by_replication():
+    """The multi-CU chain with as many chains as the GPU holds (C3 fp16: 5 workgroups per 16 utterances, all of
+    them resident at once, chains spread over every XCD so that some hand-offs cross XCDs): 50 tiles that repeat the
+    16 utterances of the teacher-forced case must repeat its samples bit for bit, chunked."""
+    import torch
+    from nv_wavenet_amd import WavenetEngine
+    case = TF_CASES["C3"]
+    s = case.shape
+    y16 = _teacher_forced(case, "wg")
+    t = util.O.gen_test_inputs(case.seed, case.prior, s, "oracle")
+    t.round_to_half()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = ncu // 5 - 1
+    B = 16 * tiles - 3                                   # ragged last tile
+    idx = np.arange(B) % s.B
+    e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, B, s.N, impl=3, tanhEmbed=True, precision=16)
+    info = e.kernelInfo(B, False)
+    assert "wavenet_chain<" in info and "chains=%d" % tiles in info, info
+    e.setEmbeddings(t.embP, t.embC)
+    for l in range(s.L):
+        e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
+    e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
+    e.setInputs(np.ascontiguousarray(t.Lh[:, :, idx, :]), np.ascontiguousarray(t.sel[:, idx]))
+    y = np.full((B, s.N), -1, dtype=np.int32)
+    assert e.run_chunks(100, None, s.N, B, y, 1)
+    e.synchronize()
+    assert e.chainStatus() == 0
+    bad = np.argwhere((y != y16[idx]).any(axis=1))
+    assert bad.size == 0, "utterance %d differs" % int(bad[0, 0])
+    e.close()
+
+
 @pytest.mark.parametrize("B", [16, 21, 100, 1000])
 def test_fp16_pipe_identical_to_single_workgroup(B):
     """wavenet_pipe (the multi-CU chain kept full: groups of 4 tiles in flight per chain, fp16 only) performs the
