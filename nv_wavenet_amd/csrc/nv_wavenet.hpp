@@ -552,6 +552,7 @@ public:
     void setConditioning(float* Lh, int numSamples, hipStream_t stream = 0) {
         assert(numSamples > 0 && numSamples <= m_maxSamples);
         m_condRaw = NULL;
+        gpuErrChk(hipMemsetAsync(m_chainStatus, 0, sizeof(unsigned), stream));   // a new utterance starts from a clean state
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, stream, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
         packConditioning(Lh, 0, numSamples, stream);
@@ -604,6 +605,7 @@ public:
         }
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
+        gpuErrChk(hipMemsetAsync(m_chainStatus, 0, sizeof(unsigned), 0));
         gpuErrChk(hipStreamSynchronize(0));
         m_condRaw = Lh;
         m_condRawSamples = numSamples;
