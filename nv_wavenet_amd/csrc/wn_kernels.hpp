@@ -429,7 +429,10 @@ WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const char* 
     // clustered and re-ordered, and now and then a fragment that is needed next ends up among the
     // youngest requests (a near-drain of the queue): pinned, C3 fp16 runs 39.0 instead of 42.0 us per
     // sample with two tiles per workgroup at batch 8192.
-    __builtin_amdgcn_sched_barrier(0);
+#ifndef WN_TAKE_SCHED_MASK
+#define WN_TAKE_SCHED_MASK 0
+#endif
+    __builtin_amdgcn_sched_barrier(WN_TAKE_SCHED_MASK);
 #endif
 #else
     (void)nidx; (void)base; (void)wrapBase; (void)laneOff; (void)rtWrapAt; (void)rtWrapDelta;

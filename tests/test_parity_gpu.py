@@ -726,3 +726,25 @@ def test_no_tanh_on_the_embedding(mode, precision):
         assert np.all(y == y_ref, axis=1).mean() >= 0.9
     assert e.chainStatus() == 0
     e.close(), o.close()
+
+
+def test_perf_cli_is_flag_compatible_with_the_reference_harness():
+    """scripts/nv_wavenet_perf.py mirrors nv_wavenet_perf.cu:203-281: same flags (-l -r -s -a -b -c -n -d -m -p -t),
+    same report lines, "Sample rate: %f kHz" at the end; the Implementation value selects the organisation."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode, kernel in ((1, "wavenet_wg<"), (3, "wavenet_chain<")):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "nv_wavenet_perf.py"), "-l", "6", "-r", "64", "-s", "128",
+                            "-a", "256", "-b", "4", "-c", "2", "-n", "512", "-d", "8", "-m", str(mode), "-p", "16", "-t", "128"],
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = r.stdout
+        for line in ("R: 64", "S: 128", "A: 256", "num layers: 6", "max dilation: 8", "batch size: 4", "batch size per block: 2",
+                     "num samples: 512", "precision: fp16"):
+            assert line in out, (line, out)
+        assert kernel in out, out
+        m = re.search(r"Sample rate: ([0-9.]+) kHz", out)
+        assert m and float(m.group(1)) > 1.0, out
