@@ -393,17 +393,18 @@ WN_DEV floatx4 agpr_pin(floatx4 v) {
     asm volatile("" : "=a"(o) : "0"(v));
     return o;
 }
-template <bool F16> WN_DEV typename Prec<F16>::frag agpr_operand(typename Prec<F16>::frag f) {
+template <bool PIN, typename FRAG> WN_DEV FRAG agpr_operand(FRAG f) {
     // fp16 builds keep the MFMA accumulators in VGPRs (-amdgpu-mfma-vgpr-form), so the AGPR file is free for
     // operands; fp32 builds (the parity mode) accumulate in AGPRs and leave the placement to the compiler
-    if constexpr (F16) return __builtin_bit_cast(typename Prec<F16>::frag, agpr_pin(__builtin_bit_cast(floatx4, f)));
+    if constexpr (PIN) return __builtin_bit_cast(FRAG, agpr_pin(__builtin_bit_cast(floatx4, f)));
     else return f;
 }
 
 // ------------------------------------------------------------------------------------------
 // weight stream: PF fragments always in flight ahead of the MFMA that consumes them
 // ------------------------------------------------------------------------------------------
-template <bool F16, int PF> struct WStream {
+// PIN: the ring lives in the accumulator file (agpr_pin); off where the AGPRs are needed as spill space instead
+template <bool F16, int PF, bool PIN = F16> struct WStream {
     typename Prec<F16>::frag buf[PF];
 };
 
@@ -412,11 +413,11 @@ template <bool F16, int PF> struct WStream {
 // slot) and refill the slot with fragment idx+PF.  The stream is contiguous across layers and into
 // the head, so the refill address is linear, except at the end of the head (WRAP = its length)
 // where it continues at `wrapBase` (layer 0 of the next sample).
-template <bool F16, int PF, int WRAP>
-WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const char* base, const char* wrapBase,
+template <bool F16, int PF, int WRAP, bool PIN>
+WN_DEV typename Prec<F16>::frag take(WStream<F16, PF, PIN>& ws, int idx, const char* base, const char* wrapBase,
                                      unsigned laneOff, int rtWrapAt = 0x7fffffff, long rtWrapDelta = 0) {
     using frag = typename Prec<F16>::frag;
-    frag a = agpr_operand<F16>(ws.buf[idx % PF]);   // the ring lives in the accumulator file (see agpr_pin)
+    frag a = agpr_operand<F16 && PIN>(ws.buf[idx % PF]);   // the ring lives in the accumulator file (see agpr_pin)
     int nidx = idx + PF;
 #ifndef WN_ABL_NOWEIGHTLOAD
     // base / wrapBase are wave-uniform (SGPR base), laneOff = lane*16.  rtWrapAt/rtWrapDelta: a
@@ -441,8 +442,8 @@ WN_DEV typename Prec<F16>::frag take(WStream<F16, PF>& ws, int idx, const char* 
 }
 
 // acc[bt][mt] += W(tile mt) * b[bt]   for MT tiles of this wave, KF k-fragments, BT batch tiles
-template <bool F16, int PF, int WRAP, int BT, int MT, int KF>
-WN_DEV void gemm(WStream<F16, PF>& ws, int pos0, const char* cur, const char* next, unsigned laneOff,
+template <bool F16, int PF, int WRAP, int BT, int MT, int KF, bool PIN>
+WN_DEV void gemm(WStream<F16, PF, PIN>& ws, int pos0, const char* cur, const char* next, unsigned laneOff,
                  floatx4 (&acc)[BT][MT], const typename Prec<F16>::frag (&b)[BT][KF], int rtWrapAt = 0x7fffffff,
                  long rtWrapDelta = 0) {
     // fragment order inside a GEMM: groups of G tile slots, k-fragment-major inside a group, so that
@@ -464,8 +465,8 @@ WN_DEV void gemm(WStream<F16, PF>& ws, int pos0, const char* cur, const char* ne
 }
 
 // same, with the B fragments read from their LDS image as they are needed (KF too large for registers)
-template <bool F16, int PF, int WRAP, int BT, int MT, int KF>
-WN_DEV void gemm_ldsb(WStream<F16, PF>& ws, int pos0, const char* cur, const char* next, unsigned laneOff,
+template <bool F16, int PF, int WRAP, int BT, int MT, int KF, bool PIN>
+WN_DEV void gemm_ldsb(WStream<F16, PF, PIN>& ws, int pos0, const char* cur, const char* next, unsigned laneOff,
                       floatx4 (&acc)[BT][MT], const char* bimg, int lane) {
     using frag = typename Prec<F16>::frag;
     constexpr int G = MT >= 4 ? 4 : MT;
@@ -713,7 +714,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     }
 
     // ---- prime the weight ring ----------------------------------------------------------------
-    WStream<F16, PF> ws;
+    // (two tiles per workgroup reading the conditioning in place need the accumulator file as spill space: ring in VGPRs)
+    WStream<F16, PF, F16 && !(RAW && BT == 2)> ws;
 #pragma unroll
     for (int i = 0; i < PF; i++) ws.buf[i] = *(const frag*)(wbase + (size_t)i * 1024 + laneOff);
 
