@@ -8,13 +8,12 @@
 //
 //   * wavenet_wg (wn_kernels.hpp) streams the whole model (1.7 MB at C3, 7.2 MB at C4) through ONE CU's
 //     vector-memory path every sample; that stream, not the arithmetic, is its floor (C4: 52 us per
-//     sample > the 41.7 us of 24 kHz).  A CU can hold ~460 KB of weights: 512 registers x 64 lanes x 4
-//     waves of which ~320 per lane are free for weights (MFMA A operands straight from the register
-//     file), plus ~130 KB of LDS (ds_read_b128 per fragment, conflict-free, 4 LDS cycles against the
-//     16-cycle MFMA it feeds).  So the layer stack is cut into STAGES of lpc consecutive layers whose
-//     weights stay on chip (C3 fp16: 5 layers per CU, C4 fp16: 2), one workgroup = 4 waves per stage,
-//     plus one HEAD stage (skip ReLU -> Zs -> Za -> softmax -> pick -> embedding of the next sample).
-//     No weight is read from memory after the prologue.
+//     sample > the 41.7 us of 24 kHz).  A CU can hold ~460 KB of weights on chip: the 256 accumulator
+//     registers of every lane (64 fragments per wave, read in place by the MFMAs once pinned there, agpr_pin),
+//     a few architectural VGPRs, and ~130 KB of LDS (one ds_read_b128 per use).  So the layer stack is cut
+//     into STAGES of lpc consecutive layers whose weights stay on chip (C3 fp16: 5 layers per CU, C4 fp16:
+//     2), one workgroup = 4 waves per stage, plus one HEAD stage (skip ReLU -> Zs -> Za -> softmax -> pick
+//     -> embedding of the next sample).  No weight is read from memory after the prologue.
 //   * A sample travels down the chain: x_l (fp32, MFMA D layout, the residual stream) from stage to
 //     stage, and behind it the running skip sums (fp32); the head closes the loop by handing the
 //     embedded next sample to stage 0.  Arithmetic, operand rounding and summation order are exactly
@@ -24,11 +23,13 @@
 //     (the reference's pipelined nv_wavenet_prev, nv_wavenet.cuh:87-129), so the arrival-to-departure
 //     path is  Wcur x -> gate -> Wres h  per layer only.  The skip GEMMs of a stage run after its x has
 //     left (off the critical path except in the last stage).
-//   * Hand-off = data-tagged 8-byte granules {value, tag = sample number in this launch + 1}, one
-//     agent-scope relaxed atomic store each (write-through to L2 / fabric: per-XCD L2s are not coherent
-//     and a CU's L1 is never refreshed by another CU's stores), swept by the consumer wave that needs
-//     them with agent-scope relaxed loads until every tag matches (MI355X_MICROARCH.md "handoff-1to1":
-//     ~1 us per hop; no flag, no fence, no ordering between granules needed).  Mailboxes are single
+//   * Hand-off = data-tagged 8-byte granules {value, tag = sample number in this launch + 1}, one relaxed
+//     atomic store each -- agent scope (write-through to the fabric: per-XCD L2s are not coherent) or, when the
+//     placement exchange at launch found producer and consumer on one XCD, workgroup scope (the line stays in
+//     the L2 they share) -- swept by the consumer wave that needs them with agent-scope relaxed loads (a CU's
+//     L1 is never refreshed by another CU's stores: they bypass it) until every tag matches; two sweep passes
+//     are kept in flight on the x path.  No flag, no fence, no ordering between granules needed
+//     (MI355X_MICROARCH.md "handoff-1to1"); measured 0.45-0.55 us from stored to received.  Mailboxes are single
 //     slots: the autoregressive loop itself is the flow control (stage s cannot receive sample t+1
 //     before the head has finished sample t, i.e. after every stage has consumed sample t).  Mailboxes
 //     are zeroed by the host before every launch, tags count within the launch.  Every spin is bounded

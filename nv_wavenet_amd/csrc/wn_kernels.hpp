@@ -35,7 +35,12 @@
 //     ahead, into register sets alternating by layer parity, at the point of the layer where the
 //     longest take-free stretch begins; every refill of the weight ring is pinned to its take.
 //   * softmax + inverse-CDF pick: logits go through LDS once; 16 lanes per utterance, reductions
-//     with cross-lane shuffles inside a 16-lane row.
+//     with DPP row operations inside a 16-lane row (softmax_pick).
+//   * Resident operands and the weight prefetch ring live in the accumulator file and are read in place by the
+//     MFMAs (agpr_pin); the conditioning comes either packed in fragment order or, RAW kernels, straight from the
+//     caller's fp32 tensor.
+//   * This header is the single-workgroup organisation and the device primitives; wn_stream.hpp (loader / consumer
+//     waves), wn_chain.hpp (multi-CU chain, resident weights) and wn_pipe.hpp (the chain kept full) build on it.
 //
 // Layouts private to the engine (produced by the pack kernels at the bottom):
 //   fragment of an M x K weight matrix: 16 rows x (16*TPF) k-values, 64 lanes x 16 B:
