@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
-"""Per-phase shader-clock breakdown (needs the WN_TIMING experiment build via NVW_LIB)."""
+"""Per-phase shader-clock breakdown of wavenet_wg / wavenet_stream (needs the WN_TIMING experiment build via NVW_LIB).
+usage: quick_phase.py [batch] [samples] [organisation: 2 = wg one tile (default), 3 = wg two tiles, 4 = stream]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 sys.argv = [sys.argv[0]] + (sys.argv[1:] or ["16", "512"])
 B, N = int(sys.argv[1]), int(sys.argv[2])
+ORG = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 import bench
 w = bench.make_weights()
-e = bench.build_engine(w, B, N)
+e = bench.build_engine(w, B, N, organisation=ORG)
 Lh, sel = bench.device_inputs(B, N, 1)
 e.setInputs(Lh, sel)
 ms = e.time_runs(1, N, B)
 P = e.getP().reshape(-1)[:12]
 names_stream = ["embed+skipinit", "layer top: bfrags/ring st/prefetch/acc init", "prev+cur gemm", "cond add + gate valu", "res gemm", "skip gemm", "dump/loop", "head gemms", "softmax+pick", "-", "-", "sel load"]
-names = names_stream if os.environ.get("NVW_MODE") == "stream" else ["embed+barrier", "layer:xb/ring/accinit", "gate gemms+gate valu+put h", "prefetch issue", "barrier h",
+names = names_stream if ORG == 4 else ["embed+barrier", "layer:xb/ring/accinit", "gate gemms+gate valu+put h", "prefetch issue", "barrier h",
          "hb read+res gemm+put x", "skip gemm+bias(+dump)", "barrier x", "head gemms", "rotate+barrier", "softmax+ybarrier", "sel load"]
 tot = P.sum()
 print("B=%d N=%d: %.2f us/sample; wave0 clock total %.0f per sample (=%.2f us @2.4GHz... clock is 100MHz-based if small)" % (B, N, 1e3*ms/N, tot/N, tot/N/2400))
