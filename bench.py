@@ -67,7 +67,9 @@ HEAD = C3                                     # the shape the headline metric is
 R, S, A, L, MAXD = HEAD.R, HEAD.S, HEAD.A, HEAD.L, HEAD.maxD
 # the device code the engine launches for the headline point (asserted against nvw_kernel_info, and pinned
 # by tests/test_parity_gpu.py::test_benchmarked_launch_*: the timed kernel is the parity-tested one)
-HEADLINE_KERNEL = "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=1,DUMP=0>"
+HEADLINE_KERNELS = {2: "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=1,DUMP=0>",     # by tiles per workgroup
+                    3: "wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0>"}
+HEADLINE_KERNEL = HEADLINE_KERNELS[2]
 
 
 def lds_bytes_per_sample(stream_mode, bt=1):
@@ -541,9 +543,9 @@ def main():
         kname = kinfo.split(" ")[0]                             # what the engine reports it launches
         stream_mode = "wavenet_stream" in kname
         chain_mode = "wavenet_chain" in kname
-        bt = 2 if "BT=2" in kname else 1
+        bt = 3 if "BT=3" in kname else 2 if "BT=2" in kname else 1
         if not args.batch and args.config == "headline" and tiles > ncu and not stream_mode:
-            assert kname == HEADLINE_KERNEL, kinfo          # the launch the parity tests pin
+            assert kname == HEADLINE_KERNELS[bt], kinfo     # the launches the parity tests pin
         # workgroups (weight-stream passes) per sample
         passes = (tiles + 3) // 4 if stream_mode else (tiles + bt - 1) // bt
         traffic = None

@@ -46,7 +46,8 @@ nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int m
  * constructor; 0 = from `implementation` and the batch size like nvw_create):
  *   1 wavenet_wg (1 or 2 tiles of 16 utterances per workgroup by batch size)   2 / 3 wavenet_wg with exactly 1 / 2
  *   4 wavenet_stream (loader / consumer waves)   5 wavenet_chain (multi-CU, resident weights, fewest CUs)
- *   6 wavenet_chain with one layer per CU   7 wavenet_pipe (the chain kept full: groups of tiles in flight, large batches).
+ *   6 wavenet_chain with one layer per CU   7 wavenet_pipe (the chain kept full: groups of tiles in flight, large batches)
+ *   8 wavenet_wg with 3 tiles per workgroup (fp16, R <= 64; two tiles otherwise).
  * Returns NULL when the shape does not fit a CU in that organisation (the reference's variants print
  * and return false for shapes they do not support, nv_wavenet_singleblock.cuh:273-286). */
 nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, int max_dilation,

@@ -59,7 +59,8 @@ enum nvwOrganisation {
     NVW_ORG_STREAM = 4,   // wn::wavenet_stream (loader / consumer waves, 4 tiles per workgroup)
     NVW_ORG_CHAIN = 5,    // wn::wavenet_chain, as many layers per CU as stay resident
     NVW_ORG_CHAIN1 = 6,   // wn::wavenet_chain, one layer per CU
-    NVW_ORG_PIPE = 7      // wn::wavenet_pipe: the chain kept full (groups of tiles in flight per chain), large batches
+    NVW_ORG_PIPE = 7,     // wn::wavenet_pipe: the chain kept full (groups of tiles in flight per chain), large batches
+    NVW_ORG_WG3 = 8       // wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64)
 };
 
 template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
@@ -231,10 +232,13 @@ protected:
     }
     bool chainFits(int lpc, int tiles) const { return lpc > 0 && chainStagesFor(m_numLayers, lpc) * tiles <= m_numCUs; }
     bool streamFits() const { return m_streamNS >= SC::MIN_NS; }
-    // The single-workgroup organisations by batch size: up to two tiles per CU run in the latency kernel
-    // (one or two tiles split over the 4 SIMDs of a CU); beyond that every SIMD gets its own tile and the
-    // weights are streamed once per CU through an LDS ring.
-    int singleOrg(int tiles) const { return (tiles > 2 * m_numCUs && streamFits()) ? NVW_ORG_STREAM : NVW_ORG_WG; }
+    // The single-workgroup organisations by batch size: up to three tiles per CU run in the latency kernel
+    // (one, two or -- fp16, R <= 64 -- three tiles split over the 4 SIMDs of a CU); beyond that every SIMD gets
+    // its own tile and the weights are streamed once per CU through an LDS ring.
+    int singleOrg(int tiles) const {
+        if (tiles > 2 * m_numCUs && tiles <= 3 * m_numCUs && wg3Fits()) return NVW_ORG_WG3;
+        return (tiles > 2 * m_numCUs && streamFits()) ? NVW_ORG_STREAM : NVW_ORG_WG;
+    }
     // Per-sample time models (microseconds) of the organisations that can run `tiles` tiles, from the
     // shape: weight bytes per sample W, layers L, CUs.  Constants measured on MI355X:
     // a CU streams 58 B/clk of weights at ~2.1 GHz beside ~0.45 us of dependent chain per layer; a chain
@@ -298,8 +302,14 @@ protected:
         return true;
     }
     // tiles per workgroup of wn::wavenet_wg for a batch of `tiles` tiles
+    static constexpr bool WG3 = F16 && R <= 64;   // shapes with a three-tile instantiation
+    bool wg3Fits() const {
+        if constexpr (WG3) return ldsFits<3>();
+        return false;
+    }
     int wgTiles(int tiles) const {
-        const bool two = m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs);
+        if (m_org == NVW_ORG_WG3 && wg3Fits()) return 3;
+        const bool two = m_org == NVW_ORG_WG2 || m_org == NVW_ORG_WG3 || (m_org == NVW_ORG_WG && tiles > m_numCUs);
         return (two && ldsFits<2>()) ? 2 : 1;
     }
 
@@ -338,7 +348,7 @@ public:
         // per workgroup may be chosen), else exactly the tiles of the batch
         {
             const int tiles = (batchSize + 15) / 16;
-            const int group = m_streamMode ? 4 : (m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs)) ? 2 : 1;
+            const int group = m_streamMode ? 4 : (isChain() || isPipe()) ? 1 : wgTiles(tiles);
             m_tiles = (tiles + group - 1) / group * group;
             if (isPipe()) m_tiles = m_pipeChains * m_pipeGroups * PC::G;
         }
@@ -421,6 +431,7 @@ public:
         if (m_supported && !isChain() && !isPipe() && !m_streamMode) {
             allowLds<1>();
             allowLds<2>();
+            if constexpr (WG3) allowLds<3>();
         }
         if (m_streamMode) {
             gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_stream<F16, R, S, A, true>,
@@ -510,8 +521,9 @@ public:
             src.Wskip = onDevice(Wskip, (size_t)S * R);
             src.Bskip = onDevice(Bskip, S);
             hipLaunchKernelGGL((wn::pack_layer_kernel<F16>), dim3(gridFor((size_t)5 * R * R + (size_t)S * R)), dim3(256), 0, 0,
-                               m_wblob + (size_t)layer * C::FLW * C::FRAG_ELEMS, b, src, R, S, C::NW,
-                               C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS, C::O_PREV, C::O_CUR, C::O_RES, C::O_SKIP);
+                               m_wblob, b, src, R, S, C::NW, C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS,
+                               (int)C::streamPos(layer, C::O_PREV, m_numLayers), (int)C::streamPos(layer, C::O_CUR, m_numLayers),
+                               (int)C::streamPos(layer, C::O_RES, m_numLayers), (int)C::streamPos(layer, C::O_SKIP, m_numLayers));
             gpuErrChk(hipGetLastError());
         }
         gpuErrChk(hipStreamSynchronize(0));
@@ -676,10 +688,16 @@ public:
             return;
         }
         const int bt = wgTiles(tiles);
-        const int nEmb = bt == 2 ? embTables<2>() : embTables<1>();
+        int nEmb = bt == 2 ? embTables<2>() : embTables<1>();
+        size_t lds = bt == 2 ? ldsNeed<2>(m_numLayers, nEmb) : ldsNeed<1>(m_numLayers, nEmb);
+        if constexpr (WG3) {
+            if (bt == 3) {
+                nEmb = embTables<3>();
+                lds = ldsNeed<3>(m_numLayers, nEmb);
+            }
+        }
         snprintf(buf, n, "wn::wavenet_wg<%s,%d,%d,%d,BT=%d,EMBLDS=%d,DUMP=%d> tiles/wg=%d wgs=%d lds=%zu",
-                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, bt, (tiles + bt - 1) / bt,
-                 bt == 2 ? ldsNeed<2>(m_numLayers, nEmb) : ldsNeed<1>(m_numLayers, nEmb));
+                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, bt, (tiles + bt - 1) / bt, lds);
     }
 
     // ---- debug getters: last generated sample's activations, reference layouts --------------
@@ -831,6 +849,9 @@ public:
                                    SC::ldsBytes(m_numLayers, m_streamNS), stream, p, m_streamNS);
             }
             result = hipGetLastError() == hipSuccess;
+        } else if (wgTiles(tiles) == 3) {
+            result = false;
+            if constexpr (WG3) result = launch<3>(p, tiles, stream);
         } else if (wgTiles(tiles) == 2) result = launch<2>(p, tiles, stream);
         else result = launch<1>(p, tiles, stream);
         if (m_pcmUser != NULL) {

@@ -51,7 +51,7 @@ nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, in
         fprintf(stderr, "nvw_create: implementation %d out of range 0..4\n", implementation);
         return NULL;
     }
-    if (organisation < NVW_ORG_AUTO || organisation > NVW_ORG_PIPE) {
+    if (organisation < NVW_ORG_AUTO || organisation > NVW_ORG_WG3) {
         fprintf(stderr, "nvw_create: organisation %d out of range 0..7\n", organisation);
         return NULL;
     }

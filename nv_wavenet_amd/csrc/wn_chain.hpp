@@ -394,11 +394,11 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
     frag wvg[LP][CC::NVG ? CC::NVG : 1];      // VGPRs: [class A | class B]
 #pragma unroll
     for (int li = 0; li < LP; li++) {
-        const char* wl = wbase + (size_t)(l0 + (li < nl ? li : 0)) * FLW * 1024;
+        const int lw = l0 + (li < nl ? li : 0);            // (the stream is in wavenet_wg's consumption order: Cfg::streamPos)
         char* const myl = wlds + (size_t)li * NLD * 1024;
 #pragma unroll
-        for (int a = 0; a < CC::FA; a++) {                 // class A: cur | res are contiguous in the stream
-            const frag f = *(const frag*)(wl + (size_t)(C::O_CUR + a) * 1024 + laneOff);
+        for (int a = 0; a < CC::FA; a++) {                 // class A: cur | res
+            const frag f = *(const frag*)(wbase + C::streamPos(lw, C::O_CUR + a, L) * 1024 + laneOff);
             if (a < CC::NAA) wag[li][a < CC::NAA ? a : 0] = agpr_pin(__builtin_bit_cast(floatx4, f));
             else if (a < CC::NAA + CC::NVA) wvg[li][a < CC::NAA + CC::NVA ? a - CC::NAA : 0] = f;
             else if (li < nl) *(frag*)(myl + (size_t)(a - CC::NAA - CC::NVA) * 1024 + laneOff) = f;
@@ -406,7 +406,7 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
 #pragma unroll
         for (int bq = 0; bq < CC::FB; bq++) {              // class B: prev, then skip
             const int idx = bq < C::FW_GATE ? C::O_PREV + bq : C::O_SKIP + (bq - C::FW_GATE);
-            const frag f = *(const frag*)(wl + (size_t)idx * 1024 + laneOff);
+            const frag f = *(const frag*)(wbase + C::streamPos(lw, idx, L) * 1024 + laneOff);
             if (bq < CC::NAB) wag[li][bq < CC::NAB ? CC::NAA + bq : 0] = agpr_pin(__builtin_bit_cast(floatx4, f));
             else if (bq < CC::NAB + CC::NLB) {
                 if (li < nl) *(frag*)(myl + (size_t)(CC::NLA + bq - CC::NAB) * 1024 + laneOff) = f;

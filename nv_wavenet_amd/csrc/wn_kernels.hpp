@@ -55,6 +55,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <stdint.h>
 
 #include <type_traits>
@@ -102,10 +103,27 @@ struct Cfg {
     static constexpr int THREADS = NW * 64;
     static constexpr int HTW = RT / NW, STW = ST / NW, ATW = AT / NW;   // tiles per wave
     static constexpr int KF_R = RT / TPF, KF_S = ST / TPF, KF_A = AT / TPF;
-    // per-wave fragment stream of one layer: prev | cur | res | skip
+    // fragments of one layer per wave, LOGICAL order: prev | cur | res | skip
     static constexpr int FW_GATE = 2 * HTW * KF_R, FW_RES = HTW * KF_R, FW_SKIP = STW * KF_R;
     static constexpr int O_PREV = 0, O_CUR = FW_GATE, O_RES = 2 * FW_GATE, O_SKIP = O_RES + FW_RES;
     static constexpr int FLW = O_SKIP + FW_SKIP;
+    // PHYSICAL order of a wave's stream = the order wavenet_wg consumes it in:
+    //   cur(0) res(0) prev(1) | cur(1) skip(0) res(1) prev(2) | ... | cur(L-1) skip(L-2) res(L-1) prev(0) | skip(L-1) | head
+    // (the skip GEMM of a layer runs under the next layer's gate arithmetic, the dilated-tap GEMM of a layer in the
+    // exchange window at the end of the layer before; prev(0) at the end belongs to the NEXT sample).  The layers
+    // still take L*FLW fragments, and the part of layer l >= 1 starts FW_SKIP fragments before l*FLW.
+    // streamPos: logical fragment i of layer l -> position in the wave's stream.
+    __host__ __device__ static constexpr size_t streamPos(int l, int i, int L) {
+        return i < O_CUR    ? (size_t)((l == 0 ? L : l) - 1) * FLW + FW_GATE + FW_RES + (i - O_PREV)
+               : i < O_RES  ? (l == 0 ? (size_t)(i - O_CUR) : (size_t)l * FLW - FW_SKIP + (i - O_CUR))
+               : i < O_SKIP ? (size_t)l * FLW + FW_GATE + (i - O_RES)
+                            : (l == L - 1 ? (size_t)L * FLW - FW_SKIP + (i - O_SKIP)
+                                          : (size_t)(l + 1) * FLW - FW_SKIP + FW_GATE + (i - O_SKIP));
+    }
+    // the same places as seen from the kernel: relative to the start of the part of layer l-1 (= (l-1)*FLW, a whole
+    // number of ring turns), so that position % PF is the ring slot
+    static constexpr int P_CUR0 = FLW, P_CUR = FLW - FW_SKIP, P_SKIP = P_CUR + FW_GATE, P_RES = FLW + FW_GATE,
+                         P_PREV = P_RES + FW_RES;
     // per-wave fragment stream of the head: zs | za
     static constexpr int FW_ZS = ATW * KF_S, FW_ZA = ATW * KF_A;
     static constexpr int FHW = FW_ZS + FW_ZA;
@@ -136,9 +154,13 @@ struct Cfg {
 #ifndef WN_HEADREGS2
 #define WN_HEADREGS2 128     // two tiles per workgroup
 #endif
+#ifndef WN_HEADREGS3
+#define WN_HEADREGS3 0       // three tiles per workgroup: the whole head is streamed
+#endif
     static constexpr int HR = !F16 ? 0
-                              : BT == 1 ? (FHW * 4 <= WN_HEADREGS ? FHW : (FW_ZA * 4 <= WN_HEADREGS ? FW_ZA : 0))
-                                        : (FW_ZA * 4 <= WN_HEADREGS2 ? FW_ZA : 0);
+                              : BT == 1 ? (FW_ZA * 4 <= WN_HEADREGS ? FW_ZA : 0)
+                              : BT == 2 ? (FW_ZA * 4 <= WN_HEADREGS2 ? FW_ZA : 0)
+                                        : (FW_ZA * 4 <= WN_HEADREGS3 ? FW_ZA : 0);
 #endif
     static constexpr int HS = FHW - HR;
     static constexpr bool HEADRES = HS == 0;              // the stream cycles over the layers only
@@ -172,7 +194,8 @@ struct Cfg {
     // Large heads (A = 1024 in fp32): the fp32 logits take the place of the zs fragment image (one
     // extra barrier between the last zs read and the first logit write), and the A x A GEMM reads its
     // B fragments from LDS as it goes instead of holding all KF_A of them in registers.
-    static constexpr bool ALIAS_LG = ZSBUF + LGBUF > 100 * 1024;
+    // (also with three tiles per workgroup: the 24 KiB it frees let the current tap's embedding table into LDS)
+    static constexpr bool ALIAS_LG = ZSBUF + LGBUF > 100 * 1024 || BT >= 3;
     static constexpr bool ZA_B_FROM_LDS = KF_A * BT * 4 > 128;
     static constexpr int OFF_X = 0, OFF_H = OFF_X + XBUF, OFF_SK = OFF_H + HBUF, OFF_ZS = OFF_SK + SKBUF;
     static constexpr int OFF_LG = ALIAS_LG ? OFF_ZS : OFF_ZS + ZSBUF;
@@ -325,11 +348,48 @@ template <> WN_DEV float gate1<false>(float a, float b) { return a * b; }
 template <> WN_DEV float gate1<true>(float a, float b) { return a * b; }
 #else
 template <> WN_DEV float gate1<false>(float a, float b) { return tanh_acc(a) * sigmoid_f(b); }
+WN_DEV float gate_finish(float ra, float rb) { return (1.0f - 2.0f * ra) * rb; }
 template <> WN_DEV float gate1<true>(float a, float b) {
-    const float t = 1.0f - 2.0f * fast_rcp(__builtin_amdgcn_exp2f(a) + 1.0f);
-    return t * fast_rcp(1.0f + __builtin_amdgcn_exp2f(b));
+    return gate_finish(fast_rcp(__builtin_amdgcn_exp2f(a) + 1.0f), fast_rcp(1.0f + __builtin_amdgcn_exp2f(b)));
 }
 #endif
+// The same gate for a pair of values in five stages (exp2 a | exp2 b | rcp | rcp | product), so that wavenet_wg can
+// issue one MFMA of an independent GEMM between two stages: a lone wave issues about two VALU instructions in the
+// time one MFMA executes, and the gate is where a layer's VALU time is.  Same operations per value as gate1
+// (bit-identical results).  fp32 engine: stage 4 is the whole accurate gate.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+template <bool F16, int ST>
+WN_DEV void gate_stage(float a0, float a1, float b0, float b1, floatx2& ea, floatx2& eb, floatx2& ra, floatx2& rb,
+                       floatx2& h) {
+#ifdef WN_ABL_NOACT
+    if constexpr (ST == 4) h = floatx2{a0 * b0, a1 * b1};
+#else
+    if constexpr (!F16) {
+        if constexpr (ST == 4) h = floatx2{gate1<false>(a0, b0), gate1<false>(a1, b1)};
+    } else {
+        if constexpr (ST == 0) ea = floatx2{__builtin_amdgcn_exp2f(a0), __builtin_amdgcn_exp2f(a1)};
+        if constexpr (ST == 1) eb = floatx2{__builtin_amdgcn_exp2f(b0), __builtin_amdgcn_exp2f(b1)};
+        if constexpr (ST == 2) {
+            const floatx2 s = ea + 1.0f;        // (v_pk_add_f32)
+            ra = floatx2{fast_rcp(s[0]), fast_rcp(s[1])};
+        }
+        if constexpr (ST == 3) {
+            const floatx2 s = eb + 1.0f;
+            rb = floatx2{fast_rcp(s[0]), fast_rcp(s[1])};
+        }
+        if constexpr (ST == 4) h = floatx2{gate_finish(ra[0], rb[0]), gate_finish(ra[1], rb[1])};
+    }
+#endif
+}
+
+// compile-time loops: f(std::integral_constant<int, I>{}) for I in [0, N) / [A, B)
+template <int A, typename F, int... I> WN_DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, A + I>{}), ...);
+}
+template <int N, typename F> WN_DEV void static_for(F&& f) { static_for_impl<0>(f, std::make_integer_sequence<int, N>{}); }
+template <int A, int B, typename F> WN_DEV void static_for_range(F&& f) {
+    static_for_impl<A>(f, std::make_integer_sequence<int, (B > A ? B - A : 0)>{});
+}
 template <bool F16> WN_DEV floatx4 gate4(floatx4 a, floatx4 b) {
     floatx4 h;
 #pragma unroll
@@ -491,6 +551,135 @@ WN_DEV void gemm_ldsb(WStream<F16, PF, PIN>& ws, int pos0, const char* cur, cons
             }
         }
     }
+}
+
+// ---- the same stream through a BUFFER resource (wavenet_wg) ----------------------------------------------------------
+// A lone wave per SIMD issues one instruction about every 5.5 clk whatever its kind, and wavenet_wg is bound by that and
+// by the latency of its loads, so the stream is read with as few instructions as possible: buffer_load
+// with the wave's stream as the resource -- the address is an SGPR byte offset + lane*16 + a 12-bit immediate, no
+// per-lane 64-bit address arithmetic, one s_add per 4 KiB of stream -- and each refill goes straight into the slot the
+// MFMAs in front of it have just read (no second register for the slot).
+// WN_TAKE_G > 1 takes the fragments of one k step together (pinning the YOUNGEST first makes one s_waitcnt vmcnt cover
+// the group: 52 -> 32 waits per two layers).  Measured slower (C3 fp16, two tiles: 30 vs 28 us per sample): a group
+// waits for its youngest fragment before its first MFMA, which shortens the 9-fragment lookahead by G-1, and at
+// ~700 clk per L2 load the stream has no slack for that.
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#ifndef WN_TAKE_G
+#define WN_TAKE_G 1          // fragments taken (waited for) together: see take_group
+#endif
+__host__ __device__ constexpr int take_g(int g, int pf) {     // group size: divides g, at most WN_TAKE_G and the ring
+    int t = g < WN_TAKE_G ? g : WN_TAKE_G;
+    t = t < pf ? t : pf;
+    while (g % t) t--;
+    return t;
+}
+WN_DEV rsrc_t make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, -1, 0x00020000); }
+// AUX: cache policy bits of the instruction (0 = default, 2 = non-temporal / streaming)
+template <typename FRAG, int AUX = 0> WN_DEV FRAG buf_load(rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(FRAG, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX));
+}
+template <typename FRAG, int AUX = 0> WN_DEV void buf_store(rsrc_t rs, unsigned voff, unsigned soff, FRAG v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), rs, voff, soff, AUX);
+}
+// fragments idx .. idx+G-1 (positions relative to basePos, a whole number of ring turns from the start of the stream)
+template <bool F16, int PF, bool PIN, int G>
+WN_DEV void take_group(WStream<F16, PF, PIN>& ws, int idx, typename Prec<F16>::frag (&a)[G]) {
+#pragma unroll
+    for (int i = G - 1; i >= 0; i--) a[i] = agpr_operand<F16 && PIN>(ws.buf[(idx + i) % PF]);
+}
+// ... and their slots refilled with fragments idx+PF .. ; past WRAP (the end of the head) the stream continues at wrapPos
+template <bool F16, int PF, int WRAP, bool PIN, int G>
+WN_DEV void refill_group(WStream<F16, PF, PIN>& ws, rsrc_t rs, int idx, int basePos, int wrapPos, unsigned laneOff) {
+    using frag = typename Prec<F16>::frag;
+#ifndef WN_ABL_NOWEIGHTLOAD
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const int nidx = idx + i + PF;
+        const bool wr = WRAP > 0 && nidx >= WRAP;
+        const int rel = wr ? nidx - WRAP : nidx;                         // compile-time after unrolling
+        const int pos = (wr ? wrapPos : basePos) + (rel & ~3);           // uniform
+        ws.buf[(idx + i) % PF] = buf_load<frag>(rs, laneOff + (unsigned)(rel & 3) * 1024u, (unsigned)pos * 1024u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// acc[bt][mt] += W(tile mt) * b[bt]   (fragment order as in gemm())
+template <bool F16, int PF, int WRAP, int BT, int MT, int KF, bool PIN>
+WN_DEV void gemm_b(WStream<F16, PF, PIN>& ws, rsrc_t rs, int pos0, int basePos, int wrapPos, unsigned laneOff,
+                   floatx4 (&acc)[BT][MT], const typename Prec<F16>::frag (&b)[BT][KF]) {
+    constexpr int G = MT >= 4 ? 4 : MT;
+#pragma unroll
+    for (int mg = 0; mg < MT / G; mg++) {
+#pragma unroll
+        for (int kf = 0; kf < KF; kf++) {
+            constexpr int TG = take_g(G, PF);
+#pragma unroll
+            for (int m0 = 0; m0 < G; m0 += TG) {
+                typename Prec<F16>::frag a[TG];
+                take_group<F16, PF, PIN, TG>(ws, pos0 + (mg * KF + kf) * G + m0, a);
+#pragma unroll
+                for (int mi = 0; mi < TG; mi++)
+#pragma unroll
+                    for (int bt = 0; bt < BT; bt++)
+                        acc[bt][mg * G + m0 + mi] = mma(a[mi], b[bt][kf], acc[bt][mg * G + m0 + mi]);
+                refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, pos0 + (mg * KF + kf) * G + m0, basePos, wrapPos, laneOff);
+            }
+        }
+    }
+}
+// same, with the B fragments read from their LDS image as they are needed (KF too large for registers)
+template <bool F16, int PF, int WRAP, int BT, int MT, int KF, bool PIN>
+WN_DEV void gemm_ldsb_b(WStream<F16, PF, PIN>& ws, rsrc_t rs, int pos0, int basePos, int wrapPos, unsigned laneOff,
+                        floatx4 (&acc)[BT][MT], const char* bimg, int lane) {
+    using frag = typename Prec<F16>::frag;
+    constexpr int G = MT >= 4 ? 4 : MT;
+#pragma unroll
+    for (int mg = 0; mg < MT / G; mg++) {
+#pragma unroll
+        for (int kf = 0; kf < KF; kf++) {
+            frag b[BT];
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) b[bt] = *(const frag*)(bimg + (((bt * KF + kf) * 64 + lane) << 4));
+            constexpr int TG = take_g(G, PF);
+#pragma unroll
+            for (int m0 = 0; m0 < G; m0 += TG) {
+                frag a[TG];
+                take_group<F16, PF, PIN, TG>(ws, pos0 + (mg * KF + kf) * G + m0, a);
+#pragma unroll
+                for (int mi = 0; mi < TG; mi++)
+#pragma unroll
+                    for (int bt = 0; bt < BT; bt++) acc[bt][mg * G + m0 + mi] = mma(a[mi], b[bt], acc[bt][mg * G + m0 + mi]);
+                refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, pos0 + (mg * KF + kf) * G + m0, basePos, wrapPos, laneOff);
+            }
+        }
+    }
+}
+// takes that only keep the ring turning (zero fragments that pad a matrix to a whole number of ring turns)
+template <bool F16, int PF, int WRAP, bool PIN, int N>
+WN_DEV void skip_frags(WStream<F16, PF, PIN>& ws, rsrc_t rs, int idx, int basePos, int wrapPos, unsigned laneOff) {
+    if constexpr (N > 0) {
+        typename Prec<F16>::frag a[N];
+        take_group<F16, PF, PIN, N>(ws, idx, a);
+        refill_group<F16, PF, WRAP, PIN, N>(ws, rs, idx, basePos, wrapPos, laneOff);
+    }
+}
+
+// same with the weight fragments loaded on the spot (launch prologue: no ring)
+template <bool F16, int BT, int MT, int KF>
+WN_DEV void gemm_direct(const char* src, unsigned laneOff, floatx4 (&acc)[BT][MT], const typename Prec<F16>::frag (&b)[BT][KF]) {
+    using frag = typename Prec<F16>::frag;
+    constexpr int G = MT >= 4 ? 4 : MT;
+#pragma unroll
+    for (int mg = 0; mg < MT / G; mg++)
+#pragma unroll
+        for (int kf = 0; kf < KF; kf++)
+#pragma unroll
+            for (int mi = 0; mi < G; mi++) {
+                const frag a = *(const frag*)(src + (size_t)((mg * KF + kf) * G + mi) * 1024 + laneOff);
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++) acc[bt][mg * G + mi] = mma(a, b[bt][kf], acc[bt][mg * G + mi]);
+            }
 }
 
 // same with register-resident weight fragments
@@ -720,9 +909,11 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 
     // ---- prime the weight ring ----------------------------------------------------------------
     // (two tiles per workgroup reading the conditioning in place need the accumulator file as spill space: ring in VGPRs)
-    WStream<F16, PF, F16 && !(RAW && BT == 2)> ws;
+    constexpr bool ws_pin = F16 && !(RAW && BT == 2);
+    WStream<F16, PF, ws_pin> ws;
+    const rsrc_t rsW = make_rsrc(wbase);      // the wave's weight stream as a buffer: fragment positions become SGPR offsets
 #pragma unroll
-    for (int i = 0; i < PF; i++) ws.buf[i] = *(const frag*)(wbase + (size_t)i * 1024 + laneOff);
+    for (int i = 0; i < PF; i++) ws.buf[i] = buf_load<frag>(rsW, laneOff + (unsigned)(i & 3) * 1024u, (unsigned)(i & ~3) * 1024u);
 
     // ---- prefetch of the dilated input + conditioning of (sample tn, layer ln) ----------------
     // ---- resident head weights ------------------------------------------------------------------
@@ -751,20 +942,34 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     char* const ringMine = (char*)p.ring + (size_t)tile0 * ringTile;
     // loads (sample tn, layer ln) into (xd, cdd); ln may run past L-1 into the next sample.
     // The conditioning buffer carries one padding sample, so (tEnd, 0..1) stays in bounds.
+    // Ring and conditioning are addressed through buffer resources as well (SGPR offsets, no per-lane pointers) and
+    // always with the streaming cache policy (cache-policy bit 1, `nt`): touched once per sample, they must not evict
+    // the weights every CU of an XCD re-reads from its L2.  (A run-time choice of the policy for small batches costs
+    // more in selects than the cached accesses save: 21.7 vs 21.0 us at 16 utterances.)  The conditioning rows (sample, layer) are requested in exactly the order they lie
+    // in memory, one per layer, so their resource just advances by one row per call.
+    const rsrc_t rsRing = make_rsrc(ringMine);
+    const unsigned ringTileB = (unsigned)ringTile;
+    const char* condNext = condMine + (size_t)p.initSample * L * condStride;
     auto prefetch = [&](int tn, int ln, Dil dl, frag (&xd)[BT][XPW], frag (&cdd)[BT][CR]) {
         if (ln >= L) { ln -= L; tn += 1; }
         const unsigned slot = (unsigned)(dl.off + (tn & (dl.d - 1)));
-        const char* rp0 = ringMine + (size_t)slot * (KF_R * 1024);
-        const char* cp0 = condMine + ((size_t)tn * L + ln) * condStride;
-#pragma unroll
-        for (int bt = 0; bt < BT; bt++) {
+        const unsigned rp0 = slot * (unsigned)(KF_R * 1024);
+        const rsrc_t rsCond = make_rsrc(condNext);
+        condNext += condStride;
 #ifndef WN_ABL_NOXP
 #pragma unroll
-            for (int i = 0; i < XPW; i++) {
-                const int k = w + NW * i;
-                if (k < KF_R) xd[bt][i] = ld_stream((const frag*)(rp0 + bt * ringTile + (size_t)k * 1024 + laneOff), nt);
+        for (int i = 0; i < XPW; i++) {
+            const int k = w + NW * i;
+            if (k < KF_R) {                  // (one uniform branch, all tiles inside)
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++)
+                    xd[bt][i] = buf_load<frag, 2>(rsRing, laneOff, rp0 + (unsigned)bt * ringTileB + (unsigned)k * 1024u);
             }
-#else
+        }
+#endif
+#pragma unroll
+        for (int bt = 0; bt < BT; bt++) {
+#ifdef WN_ABL_NOXP
             // timing experiment: a value the compiler cannot fold (keeps all downstream work alive)
 #pragma unroll
             for (int i = 0; i < XPW; i++)
@@ -784,7 +989,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             } else {
 #pragma unroll
                 for (int k = 0; k < C::COND_FR; k++)
-                    cdd[bt][k] = ld_stream((const frag*)(cp0 + (size_t)bt * NW * C::COND_FR * 1024 + k * 1024 + laneOff), nt);
+                    cdd[bt][k] = buf_load<frag, 2>(rsCond, laneOff + (unsigned)(k & 3) * 1024u,
+                                                   (unsigned)((bt * NW * C::COND_FR + (k & ~3)) * 1024));
             }
 #else
 #pragma unroll
@@ -797,16 +1003,28 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     prefetch(p.initSample, 0, dil_first(), xpA, cdA);
     prefetch(p.initSample, 1, dil_next(dil_first(), p.maxDilation, false), xpB, cdB);
     // publish this wave's fragments of the NEXT layer's dilated tap to LDS
-    auto publish_xp = [&](const frag (&xpN)[BT][XPW]) {
+    // (before the start, t < d, the tap is zero -- reference :287: zeros are published then; two store sequences under
+    // a uniform branch rather than selects on the fragments, the zero case is the first d samples only)
+    auto publish_xp = [&](const frag (&xpN)[BT][XPW], const bool have) {
 #pragma unroll
-        for (int bt = 0; bt < BT; bt++)
+        for (int i = 0; i < XPW; i++) {
+            const int k = w + NW * i;
+            if (k < KF_R) {
+                if (have) {
 #pragma unroll
-            for (int i = 0; i < XPW; i++) {
-                const int k = w + NW * i;
-                if (k < KF_R) *(frag*)(xpbuf + ((bt * KF_R + k) * 64 + lane) * 16) = xpN[bt][i];
+                    for (int bt = 0; bt < BT; bt++) *(frag*)(xpbuf + ((bt * KF_R + k) * 64 + lane) * 16) = xpN[bt][i];
+                } else {
+                    asm volatile("");                  // (keeps this a branch)
+                    frag z;
+#pragma unroll
+                    for (int e = 0; e < P::EPL; e++) z[e] = (elem)0.f;
+#pragma unroll
+                    for (int bt = 0; bt < BT; bt++) *(frag*)(xpbuf + ((bt * KF_R + k) * 64 + lane) * 16) = z;
+                }
             }
+        }
     };
-    publish_xp(xpA);   // layer 0 of the first sample (ordered by the embedding barrier)
+    publish_xp(xpA, p.initSample >= 1);   // layer 0 (d = 1) of the first sample
 
     __syncthreads();   // bias table visible
 
@@ -832,6 +1050,39 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
         for (int e = 0; e < P::EPL; e++)
             selA[tt][e] = (elem)(((e >> 2) == tt && g * 4 + (e & 3) == j) ? 1.0f : 0.0f);
+    // acc: gate pre-activation of the next layer to run (see the layer schedule below).  For layer 0 of the first
+    // sample it is formed here: bias + conditioning + dilated tap, the tap's weights read straight from their place
+    // at the end of the layer stream.
+    floatx4 acc[BT][2 * HTW];
+    {
+        frag xp[BT][KF_R];
+#pragma unroll
+        for (int bt = 0; bt < BT; bt++) {
+            lds_get_frags<F16, KF_R>(xpbuf + bt * KF_R * 1024, lane, xp[bt]);
+#pragma unroll
+            for (int i = 0; i < HTW; i++) {
+                acc[bt][2 * i] = *(const floatx4*)(biasLds + (w + NW * i) * 16 + g * 4);
+                acc[bt][2 * i + 1] = *(const floatx4*)(biasLds + (w + NW * i + RT) * 16 + g * 4);
+            }
+        }
+        if constexpr (F16) {
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                    for (int tt = 0; tt < P::TPF; tt++)
+                        acc[bt][k * P::TPF + tt] = mma(selA[tt], cond_frag<F16, RAW>(cdA[bt], k), acc[bt][k * P::TPF + tt]);
+        } else {
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                    for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cdA[bt][k][e];
+        }
+        gemm_direct<F16, BT, 2 * HTW, KF_R>(wbase + C::streamPos(0, C::O_PREV, L) * 1024, laneOff, acc, xp);
+    }
     const int tEnd = p.initSample + p.count;
     for (int t = p.initSample; t < tEnd; t++) {
         const bool dumpNow = DUMP && p.dump && (t == tEnd - 1);
@@ -877,139 +1128,128 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             for (int i = 0; i < STW; i++) skip[bt][i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
         // ---- L dilated layers (nv_wavenet_reference.cpp:58-92) -------------------------------
-        // Schedule of one layer for a wave (critical path: x exchange -> cur GEMM -> gate -> h
-        // exchange -> res GEMM -> x exchange).  The skip GEMM of layer l-1 and the dilated-tap
-        // GEMM of layer l do not depend on x_l, so they are issued first and run while the x
-        // fragments come back from LDS; the weight stream order [prev|cur|res|skip] per layer is
-        // consumed as  prev(0) cur(0) res(0) | skip(0) prev(1) cur(1) res(1) | ... | skip(L-1).
+        // Schedule of one layer for a wave.  Critical path: x exchange -> cur GEMM -> gate -> h exchange -> res GEMM
+        // -> x exchange.  Everything else runs where that path leaves the matrix core idle:
+        //  * the skip GEMM of layer l-1 is issued MFMA by MFMA between the stages of the gate arithmetic of layer l
+        //    (a lone wave issues ~2 VALU instructions while one MFMA executes);
+        //  * bias + conditioning + dilated-tap GEMM of layer l+1 (which do not depend on x_{l+1}) are formed around
+        //    the x exchange that ends layer l: conditioning MFMAs while the x stores drain, the tap GEMM while the
+        //    x fragments come back from LDS.  acc therefore always holds the pre-activation of the NEXT layer to run.
+        // The weight stream is laid out in exactly this order (Cfg::streamPos).
         frag hb[BT][KF_R];
-        // (xpC, cdC): register set of this layer's parity -- its conditioning is consumed by the gate,
-        // its dilated tap was published at the end of the previous layer, and the prefetch for layer
-        // l+2 refills it; xpN: the other set, holding the tap of layer l+1 (published at the end).
-        auto layer = [&](auto withSkip, const int l, const Dil dl, const Dil dl2, frag (&xpC)[BT][XPW],
-                         frag (&cdC)[BT][CR], const frag (&xpN)[BT][XPW]) {
+        frag xb[BT][KF_R];
+#pragma unroll
+        for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(xbuf + bt * KF_R * 1024, lane, xb[bt]);
+        // (xpC, cdC): register set of this layer's parity: both were consumed during the previous layer (tap
+        // published, conditioning added), the prefetch for layer l+2 refills them; (xpN, cdN): the other set,
+        // holding tap and conditioning of layer l+1.  dN: dilation of layer l+1, tN: the sample it belongs to.
+        auto layer = [&](auto withSkip, const int l, const Dil dl, const Dil dN, const Dil dl2, frag (&xpC)[BT][XPW],
+                         frag (&cdC)[BT][CR], const frag (&xpN)[BT][XPW], const frag (&cdN)[BT][CR]) {
             constexpr bool SKIP = decltype(withSkip)::value;
-            // fragment positions are relative to the start of layer l-1 (SKIP) / layer l
-            const char* wl = wbase + (size_t)(SKIP ? l - 1 : l) * FLW * 1024;
-            constexpr int OFS = SKIP ? FLW : 0;
-            // with resident head weights the stream cycles over the layers only: prefetches that
-            // run past the last layer continue at layer 0
-            const int wrapAt = C::HEADRES ? (L - (SKIP ? l - 1 : l)) * FLW : 0x7fffffff;
-            const long wrapDelta = C::HEADRES ? -(long)L * FLW * 1024 : 0;
+            const int wl = (l - 1) * FLW;   // fragment positions (Cfg::P_*) count from the start of the part of layer l-1
             const float* bl = biasLds + l * C::BIAS_L;
+            const int lN = l + 1 < L ? l + 1 : 0;
+            const float* blN = biasLds + lN * C::BIAS_L;
             const int d = dl.d;
-            const bool havePrev = t >= d;
+            const bool havePrevN = (l + 1 < L ? t : t + 1) >= dN.d;
 
-            // x as B fragments (LDS), accumulators start at the gate bias
-            frag xb[BT][KF_R];
-            floatx4 acc[BT][2 * HTW];
-#pragma unroll
-            for (int bt = 0; bt < BT; bt++) {
-                lds_get_frags<F16, KF_R>(xbuf + bt * KF_R * 1024, lane, xb[bt]);
-#pragma unroll
-                for (int i = 0; i < HTW; i++) {
-                    acc[bt][2 * i] = *(const floatx4*)(bl + (w + NW * i) * 16 + g * 4);
-                    acc[bt][2 * i + 1] = *(const floatx4*)(bl + (w + NW * i + RT) * 16 + g * 4);
-                }
-            }
-            // + conditioning (summation order of the gate pre-activation in every organisation of the engine:
-            // bias, conditioning, dilated tap, current tap -- the multi-CU chain forms the first three while it
-            // waits for the sample).  fp16: a fragment in B layout already, added by the matrix core through a
-            // 0/1 selection matrix (2 MFMAs instead of 8 conversions + 8 adds per fragment)
-            if constexpr (F16) {
-#pragma unroll
-                for (int bt = 0; bt < BT; bt++)
-#pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int tt = 0; tt < P::TPF; tt++)
-                            acc[bt][k * P::TPF + tt] = mma(selA[tt], cond_frag<F16, RAW>(cdC[bt], k), acc[bt][k * P::TPF + tt]);
-            } else {
-#pragma unroll
-                for (int bt = 0; bt < BT; bt++)
-#pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cdC[bt][k][e];
-            }
-            // deferred skip GEMM of the previous layer: skip <- Wskip h + skip
-            if constexpr (SKIP) {
-                gemm<F16, PF, 0, BT, STW, KF_R>(ws, C::O_SKIP, wl, wl, laneOff, skip, hb, wrapAt, wrapDelta);
-                if (dumpNow) {
-                    const float* bp = biasLds + (l - 1) * C::BIAS_L + 3 * R;   // running bias sum
-#pragma unroll
-                    for (int bt = 0; bt < BT; bt++) {
-                        if (!uvalid[bt]) continue;
-#pragma unroll
-                        for (int i = 0; i < STW; i++)
-                            *(floatx4*)(p.skipOut + ((size_t)(l - 1) * p.maxBatch + ub[bt]) * S + (w + NW * i) * 16 + g * 4) =
-                                skip[bt][i] + *(const floatx4*)(bp + (w + NW * i) * 16 + g * 4);
-                    }
-                }
-            }
-            // dilated tap: x_l[t-d] was prefetched and published to LDS by its owners during the
-            // previous layer; zero before the start (reference :287)
-            frag xp[BT][KF_R];
-#pragma unroll
-            for (int bt = 0; bt < BT; bt++) {
-                lds_get_frags<F16, KF_R>(xpbuf + bt * KF_R * 1024, lane, xp[bt]);
-#pragma unroll
-                for (int k = 0; k < KF_R; k++) {
-                    if (!havePrev) {
-#pragma unroll
-                        for (int e = 0; e < P::EPL; e++) xp[bt][k][e] = (elem)0.f;
-                    }
-                }
-            }
+            // current tap on top of bias + conditioning + dilated tap (xb: x as B fragments, requested behind the
+            // x barrier)
             WN_TMARK(1)
-            gemm<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, OFS + C::O_PREV, wl, wl, laneOff, acc, xp, wrapAt, wrapDelta);
-            // x_l[t] replaces x_l[t-d] in the ring (same slot), then the current tap
-#pragma unroll
-            for (int bt = 0; bt < BT; bt++) {
-                char* rp = ringMine + bt * ringTile + (size_t)(unsigned)(dl.off + (t & (d - 1))) * (KF_R * 1024);
+            gemm_b<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, rsW, SKIP ? C::P_CUR : C::P_CUR0, wl, 0, laneOff, acc, xb);
+            // x_l[t] replaces x_l[t-d] in the ring (same slot)
+            {
+                const unsigned rp = (unsigned)(dl.off + (t & (d - 1))) * (unsigned)(KF_R * 1024);
 #pragma unroll
                 for (int k = 0; k < KF_R; k++)
-                    if (k % NW == w) st_stream((frag*)(rp + k * 1024 + laneOff), xb[bt][k], nt);
+                    if (k % NW == w) {       // (one uniform branch per fragment index, all tiles inside)
+#pragma unroll
+                        for (int bt = 0; bt < BT; bt++)
+                            buf_store<frag, 2>(rsRing, laneOff + (unsigned)(k & 3) * 1024u,
+                                               rp + (unsigned)bt * ringTileB + (unsigned)(k & ~3) * 1024u, xb[bt][k]);
+                    }
             }
-            gemm<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, OFS + C::O_CUR, wl, wl, laneOff, acc, xb, wrapAt, wrapDelta);
-#ifndef WN_PREFETCH_LATE
-            // VMEM returns in order: the first weight fragment requested AFTER these HBM loads is taken
-            // by the next layer's GEMMs, so issuing them here, ahead of the take-free gate / exchange
-            // phases, gives them the longest time to land before anything queues behind them
+            // Dilated tap and conditioning of layer l+2 (HBM) into the register set this layer has finished with.  VMEM
+            // returns in order: the first weight fragment requested AFTER these loads is taken PF takes later, i.e.
+            // behind the gate and the h exchange -- the longest stretch of a layer without a dependence on new weights.
             prefetch(t, l + 2, dl2, xpC, cdC);
             __builtin_amdgcn_sched_barrier(0);
-#endif
-
-            // gate -> h tiles of this wave -> LDS
-#pragma unroll
-            for (int bt = 0; bt < BT; bt++)
-#pragma unroll
-                for (int i = 0; i < HTW; i++) {
-                    const floatx4 hv = gate4<F16>(acc[bt][2 * i], acc[bt][2 * i + 1]);
-                    lds_put_tile<F16>(hbuf + bt * KF_R * 1024, w + NW * i, lane, hv);
-                }
             WN_TMARK(2)
+
+            // gate -> h tiles of this wave -> LDS, in stages (pairs of values: exp2 a | exp2 b | rcp | rcp | product)
+            // with the MFMAs of the previous layer's skip GEMM in between:  skip <- Wskip h + skip
+            {
+                constexpr int NS = BT * HTW * 2 * 5;                  // gate stages
+                constexpr int NM = SKIP ? STW * KF_R * BT : 0;        // MFMA slots
+                floatx2 ea, eb, ra, rb, hp;
+                floatx4 hv;
+                auto stage = [&](auto SI) {
+                    constexpr int s = decltype(SI)::value, pr = s / 5, st = s % 5;
+                    constexpr int bt = pr / (2 * HTW), i = (pr / 2) % HTW, r = (pr & 1) * 2;
+                    gate_stage<F16, st>(acc[bt][2 * i][r], acc[bt][2 * i][r + 1], acc[bt][2 * i + 1][r], acc[bt][2 * i + 1][r + 1],
+                                        ea, eb, ra, rb, hp);
+                    if constexpr (st == 4) {
+                        hv[r] = hp[0];
+                        hv[r + 1] = hp[1];
+                        if constexpr (r == 2) lds_put_tile<F16>(hbuf + bt * KF_R * 1024, w + NW * i, lane, hv);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                if constexpr (SKIP) {
+                    constexpr int G0 = STW >= 4 ? 4 : STW, G = take_g(G0, PF);
+                    static_for<STW * KF_R / G>([&](auto GI) {           // groups of takes inside a k step (see gemm_b)
+                        constexpr int gi = decltype(GI)::value, q = gi * G;      // q: first fragment of the group
+                        constexpr int kf = (q / G0) % KF_R, mg = q / (G0 * KF_R), mi0 = q % G0;
+                        frag a[G];
+                        take_group<F16, PF, ws_pin, G>(ws, C::P_SKIP + gi * G, a);
+                        static_for<G * BT>([&](auto MI) {
+                            constexpr int mi = decltype(MI)::value / BT, bt = decltype(MI)::value % BT;
+                            constexpr int mt = mg * G0 + mi0 + mi, m = (q + mi) * BT + bt;
+                            skip[bt][mt] = mma(a[mi], hb[bt][kf], skip[bt][mt]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            static_for_range<m * NS / NM, (m + 1) * NS / NM>(stage);
+                        });
+                        refill_group<F16, PF, 0, ws_pin, G>(ws, rsW, C::P_SKIP + gi * G, wl, 0, laneOff);
+                    });
+                    if (dumpNow) {
+                        const float* bp = biasLds + (l - 1) * C::BIAS_L + 3 * R;   // running bias sum
+#pragma unroll
+                        for (int bt = 0; bt < BT; bt++) {
+                            if (!uvalid[bt]) continue;
+#pragma unroll
+                            for (int i = 0; i < STW; i++)
+                                *(floatx4*)(p.skipOut + ((size_t)(l - 1) * p.maxBatch + ub[bt]) * S + (w + NW * i) * 16 + g * 4) =
+                                    skip[bt][i] + *(const floatx4*)(bp + (w + NW * i) * 16 + g * 4);
+                        }
+                    }
+                } else {
+                    static_for<NS>(stage);
+                }
+            }
+            WN_TMARK(3)
             wg_barrier();   // h complete
             WN_TMARK(4)
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(hbuf + bt * KF_R * 1024, lane, hb[bt]);
 
-            // residual accumulators start at Bres + x; the dilated input / conditioning of layer
-            // l+2 are requested while the h fragments come back from LDS
+            // residual accumulators start at Bres + x
             floatx4 xa[BT][HTW];
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
                 for (int i = 0; i < HTW; i++)
                     xa[bt][i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[bt][i];
-#ifdef WN_PREFETCH_LATE
-            prefetch(t, l + 2, dl2, xpC, cdC);
-#endif
-            WN_TMARK(3)
+            // the next layer's accumulators start at its gate bias
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int i = 0; i < HTW; i++) {
+                    acc[bt][2 * i] = *(const floatx4*)(blN + (w + NW * i) * 16 + g * 4);
+                    acc[bt][2 * i + 1] = *(const floatx4*)(blN + (w + NW * i + RT) * 16 + g * 4);
+                }
 
             // residual: x <- Wres h + Bres + x  (this wave's tiles) -> LDS
-            gemm<F16, PF, 0, BT, HTW, KF_R>(ws, OFS + C::O_RES, wl, wl, laneOff, xa, hb, wrapAt, wrapDelta);
-
+            gemm_b<F16, PF, 0, BT, HTW, KF_R>(ws, rsW, C::P_RES, wl, 0, laneOff, xa, hb);
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
@@ -1017,7 +1257,31 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     x[bt][i] = xa[bt][i];
                     lds_put_tile<F16>(xbuf + bt * KF_R * 1024, w + NW * i, lane, xa[bt][i]);
                 }
+            // dilated tap of layer l+1 (layer 0 of the next sample after the last layer), requested one and a half layers
+            // ago: shared through LDS with the x exchange (the readers of the previous tap passed the h barrier)
+            publish_xp(xpN, havePrevN);
+            __builtin_amdgcn_sched_barrier(0);
             WN_TMARK(5)
+            // + conditioning of the next layer while the x stores drain (summation order of the gate pre-activation in
+            // every organisation of the engine: bias, conditioning, dilated tap, current tap).  fp16: a fragment in B
+            // layout already, added by the matrix core through a 0/1 selection matrix (2 MFMAs instead of 8
+            // conversions + 8 adds per fragment)
+            if constexpr (F16) {
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                        for (int tt = 0; tt < P::TPF; tt++)
+                            acc[bt][k * P::TPF + tt] = mma(selA[tt], cond_frag<F16, RAW>(cdN[bt], k), acc[bt][k * P::TPF + tt]);
+            } else {
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                    for (int k = 0; k < C::COND_FR; k++)
+#pragma unroll
+                        for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cdN[bt][k][e];
+            }
             if (dumpNow) {
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++) {
@@ -1027,32 +1291,40 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         *(floatx4*)(p.xtOut + ((size_t)l * p.maxBatch + ub[bt]) * R + (w + NW * i) * 16 + g * 4) = x[bt][i];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             WN_TMARK(6)
-            publish_xp(xpN);   // dilated tap of layer l+1 (layer 0 of the next sample after the last layer)
             wg_barrier();   // x complete
             WN_TMARK(7)
+            // the next layer's tap and x fragments are requested; the dilated-tap GEMM runs while the latter come back
+            frag xp[BT][KF_R];
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(xpbuf + bt * KF_R * 1024, lane, xp[bt]);
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(xbuf + bt * KF_R * 1024, lane, xb[bt]);
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_b<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, rsW, C::P_PREV, wl, 0, laneOff, acc, xp);
         };
         {
+            // dK = schedule entry of layer (l+K) mod L  (l+1, l+2 may wrap into the next sample)
             Dil d0 = dil_first();
-            Dil d1 = dil_next(d0, p.maxDilation, 1 >= L);
-            Dil d2 = dil_next(d1, p.maxDilation, 2 >= L && 2 - L == 0);
-            // dK = schedule entry of layer (l+K) mod L, (l+2 may wrap into the next sample)
-            layer(std::false_type{}, 0, d0, d2, xpA, cdA, xpB);
+            Dil d1 = dil_next(d0, p.maxDilation, false);
+            Dil d2 = dil_next(d1, p.maxDilation, L == 2);
+            layer(std::false_type{}, 0, d0, d1, d2, xpA, cdA, xpB, cdB);
             auto step = [&](const int l) {
                 d0 = d1;
                 d1 = d2;
-                d2 = dil_next(d1, p.maxDilation, l + 2 == L);   // layer l+2 == L is layer 0 of the next sample
+                d2 = dil_next(d1, p.maxDilation, l + 2 == L);   // layer index L is layer 0 of the next sample
             };
             int l = 1;
             for (; l + 1 < L; l += 2) {
                 step(l);
-                layer(std::true_type{}, l, d0, d2, xpB, cdB, xpA);
+                layer(std::true_type{}, l, d0, d1, d2, xpB, cdB, xpA, cdA);
                 step(l + 1);
-                layer(std::true_type{}, l + 1, d0, d2, xpA, cdA, xpB);
+                layer(std::true_type{}, l + 1, d0, d1, d2, xpA, cdA, xpB, cdB);
             }
             if (l < L) {
                 step(l);
-                layer(std::true_type{}, l, d0, d2, xpB, cdB, xpA);
+                layer(std::true_type{}, l, d0, d1, d2, xpB, cdB, xpA, cdA);
             }
             if (L & 1) {
                 // odd layer count: layer 0 of the next sample was prefetched into the odd set
@@ -1074,8 +1346,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             }
         }
         // skip GEMM of the last layer
-        gemm<F16, PF, 0, BT, STW, KF_R>(ws, C::O_SKIP, wbase + (size_t)(L - 1) * FLW * 1024, wbase, laneOff, skip, hb,
-                                        C::HEADRES ? FLW : 0x7fffffff, C::HEADRES ? -(long)L * FLW * 1024 : 0);
+        gemm_b<F16, PF, 0, BT, STW, KF_R>(ws, rsW, C::P_CUR, (L - 1) * FLW, 0, laneOff, skip, hb);
 
         // ---- output head (nv_wavenet_reference.cpp:94-104) -----------------------------------
 #pragma unroll
@@ -1102,9 +1373,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             }
             if constexpr (HS == 0) gemm_res<F16, BT, ATW, KF_S>(hw, 0, zs, sb);
             else {
-                gemm<F16, PF, C::HSP, BT, ATW, KF_S>(ws, C::O_ZS, whead, wbase, laneOff, zs, sb);
-#pragma unroll
-                for (int i = 0; i < C::PAD1; i++) (void)take<F16, PF, C::HSP>(ws, C::FW_ZS + i, whead, wbase, laneOff);   // (zero fragments)
+                gemm_b<F16, PF, C::HSP, BT, ATW, KF_S>(ws, rsW, C::O_ZS, L * FLW, 0, laneOff, zs, sb);
+                skip_frags<F16, PF, C::HSP, ws_pin, C::PAD1>(ws, rsW, C::FW_ZS, L * FLW, 0, laneOff);   // (zero fragments)
             }
         }
 #pragma unroll
@@ -1127,13 +1397,13 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     za[bt][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
             if constexpr (C::ZA_B_FROM_LDS) {
                 static_assert(HR == 0, "the LDS-streamed head is for the large, non-resident heads");
-                gemm_ldsb<F16, PF, C::HSP, BT, ATW, KF_A>(ws, C::O_ZA, whead, wbase, laneOff, za, zsbuf, lane);
+                gemm_ldsb_b<F16, PF, C::HSP, BT, ATW, KF_A>(ws, rsW, C::O_ZA, L * FLW, 0, laneOff, za, zsbuf, lane);
             } else {
                 frag zb[BT][KF_A];
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_A>(zsbuf + bt * KF_A * 1024, lane, zb[bt]);
                 if constexpr (HR >= C::FW_ZA) gemm_res<F16, BT, ATW, KF_A>(hw, C::FW_ZS - HS, za, zb);
-                else gemm<F16, PF, C::HSP, BT, ATW, KF_A>(ws, C::O_ZA, whead, wbase, laneOff, za, zb);
+                else gemm_b<F16, PF, C::HSP, BT, ATW, KF_A>(ws, rsW, C::O_ZA, L * FLW, 0, laneOff, za, zb);
             }
             if constexpr (C::ALIAS_LG) wg_barrier();   // every wave is done with the zs image
             // logits -> LDS [utt][row] (row stride padded by 4 floats: conflict-free b128 writes)
@@ -1148,8 +1418,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         }
         WN_TMARK(8)
         if constexpr (HS == FHW) {
-#pragma unroll
-            for (int i = 0; i < C::PAD2; i++) (void)take<F16, PF, C::HSP>(ws, C::O_ZA + C::FW_ZA + i, whead, wbase, laneOff);   // (zero fragments)
+            skip_frags<F16, PF, C::HSP, ws_pin, C::PAD2>(ws, rsW, C::O_ZA + C::FW_ZA, L * FLW, 0, laneOff);   // (zero fragments)
         }
         wg_barrier();
         WN_TMARK(9)

@@ -205,11 +205,11 @@ WN_DEV void pipe_layers(const Params& p, const PipeParams& pp, char* lds, int ch
     floatx4 wag[PC::NAG ? PC::NAG : 1];
 #pragma unroll
     for (int li = 0; li < LP; li++) {
-        const char* wl = wbase + (size_t)(l0 + (li < nl ? li : 0)) * FLW * 1024;
+        const int lw = l0 + (li < nl ? li : 0);            // (the stream is in wavenet_wg's consumption order: Cfg::streamPos)
 #pragma unroll
         for (int i = 0; i < FLW; i++) {
             const int pos = li * FLW + i;
-            const frag f = *(const frag*)(wl + (size_t)i * 1024 + laneOff);
+            const frag f = *(const frag*)(wbase + C::streamPos(lw, i, L) * 1024 + laneOff);
             if (pos < PC::NAG) wag[pos < PC::NAG ? pos : 0] = agpr_pin(__builtin_bit_cast(floatx4, f));
             else if (li < nl) *(frag*)(wlds + (size_t)(pos - PC::NAG) * 1024 + laneOff) = f;
         }

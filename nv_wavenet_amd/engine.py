@@ -31,7 +31,8 @@ class Org:
     CHAIN = 5       # wn::wavenet_chain: multi-CU, weights resident, fewest CUs
     CHAIN1 = 6      # wn::wavenet_chain, one layer per CU
     PIPE = 7        # wn::wavenet_pipe: the chain kept full (throughput, large batches)
-    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "stream": 4, "chain": 5, "chain1": 6, "pipe": 7}
+    WG3 = 8         # wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64; else two)
+    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "stream": 4, "chain": 5, "chain1": 6, "pipe": 7, "wg3": 8}
 
 
 def supported_configs():
@@ -63,8 +64,8 @@ class WavenetEngine:
         self.precision = precision
         if isinstance(organisation, str) or organisation is None:
             organisation = Org.BY_NAME[organisation]
-        if organisation not in range(8):
-            raise ValueError("organisation must be 0..7")
+        if organisation not in range(9):
+            raise ValueError("organisation must be 0..8")
         self._h = lib.nvw_create_ex(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
                                     1 if tanhEmbed else 0, organisation)
         if not self._h:

@@ -15,8 +15,8 @@ e.setInputs(Lh, sel)
 ms = e.time_runs(1, N, B)
 P = e.getP().reshape(-1)[:12]
 names_stream = ["embed+skipinit", "layer top: bfrags/ring st/prefetch/acc init", "prev+cur gemm", "cond add + gate valu", "res gemm", "skip gemm", "dump/loop", "head gemms", "softmax+pick", "-", "-", "sel load"]
-names = names_stream if ORG == 4 else ["embed+barrier", "layer:xb/ring/accinit", "gate gemms+gate valu+put h", "prefetch issue", "barrier h",
-         "hb read+res gemm+put x", "skip gemm+bias(+dump)", "barrier x", "head gemms", "rotate+barrier", "softmax+ybarrier", "sel load"]
+names = names_stream if ORG == 4 else ["embed+barrier", "xb read + tap gemm (prev layer's tail)", "cur gemm+ring st+prefetch", "gate || skip gemm + publish tap", "barrier h",
+         "hb/xp read+res gemm+put x", "cond mfma(+dump)", "barrier x", "head gemms", "pad takes+barrier", "softmax+ybarrier", "sel load"]
 tot = P.sum()
 print("B=%d N=%d: %.2f us/sample; wave0 clock total %.0f per sample (=%.2f us @2.4GHz... clock is 100MHz-based if small)" % (B, N, 1e3*ms/N, tot/N, tot/N/2400))
 L = bench.L

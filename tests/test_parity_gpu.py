@@ -301,6 +301,43 @@ def test_fp16_pipe_identical_to_single_workgroup(B):
     e.close()
 
 
+@pytest.mark.parametrize("B", [16, 40, 100])
+def test_fp16_three_tiles_per_workgroup_identical(B):
+    """wavenet_wg with three tiles of 16 utterances per workgroup (organisation 8: the launch shape of 8193 .. 12288
+    utterances per GPU) against the one-tile kernel, which the oracle checks teacher-forced: one tile in a group of three,
+    one partly filled group, several groups; one launch and chunked; packed conditioning and conditioning read in place."""
+    import torch
+    from nv_wavenet_amd import WavenetEngine
+    case = TF_CASES["C3"]
+    s = case.shape
+    y16 = _teacher_forced(case, "wg")
+    t = util.O.gen_test_inputs(case.seed, case.prior, s, "oracle")
+    t.round_to_half()
+    idx = np.arange(B) % s.B
+    e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, B, s.N, impl=0, tanhEmbed=True, precision=16, organisation=util.MODE_ORG["wg3"])
+    assert "wavenet_wg<" in e.kernelInfo(B, False) and "BT=3" in e.kernelInfo(B, False), e.kernelInfo(B, False)
+    e.setEmbeddings(t.embP, t.embC)
+    for l in range(s.L):
+        e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
+    e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
+    Lh = np.ascontiguousarray(t.Lh[:, :, idx, :])
+    sel = np.ascontiguousarray(t.sel[:, idx])
+    Lh_dev = torch.from_numpy(Lh).cuda()
+    for chunk, direct in ((None, False), (100, False), (None, True)):
+        e.setInputs(Lh, sel)
+        if direct:
+            e.setConditioningDirect(Lh_dev)
+        y = np.full((B, s.N), -1, dtype=np.int32)
+        if chunk:
+            assert e.run_chunks(chunk, None, s.N, B, y, 1)
+        else:
+            assert e.run(s.N, B, y, 1, False)
+        e.synchronize()
+        bad = np.argwhere((y != y16[idx]).any(axis=1))
+        assert bad.size == 0, "utterance %d differs (chunk %s, in place %s)" % (int(bad[0, 0]), chunk, direct)
+    e.close()
+
+
 @pytest.mark.parametrize("precision", [32, 16])
 @pytest.mark.parametrize("mode", ["wg", "wg2", "chain"])
 def test_conditioning_consumed_in_place(mode, precision):
@@ -356,10 +393,11 @@ def test_conditioning_consumed_in_place(mode, precision):
     e.close()
 
 
-def test_benchmarked_launch_is_the_parity_tested_one():
+@pytest.mark.parametrize("tiles_per_cu", [2, 3])
+def test_benchmarked_launch_is_the_parity_tested_one(tiles_per_cu):
     """What bench.py times by default IS pinned: C3 at BASELINE depth and dilation range (R64/S256/A256, 20 layers,
-    maxDilation 512, fp16) at two tiles per CU -- the engine then launches wavenet_wg with two tiles per workgroup,
-    no dump code, non-temporal ring / conditioning traffic.  The big batch repeats 16 utterances (conditioning
+    maxDilation 512, fp16) at two or three tiles per CU -- the engine then launches wavenet_wg with that many tiles per
+    workgroup, no dump code, non-temporal ring / conditioning traffic.  The big batch repeats 16 utterances (conditioning
     tiled on the device), N = 640 samples so the d = 512 taps are live and the rings wrap, and must reproduce, bit
     for bit, the 16-utterance run of the one-tile kernel -- which itself is held to the fp32 oracle teacher-forced
     (>= 99.5 % of picks identical, every other one a CDF-edge case)."""
@@ -372,10 +410,10 @@ def test_benchmarked_launch_is_the_parity_tested_one():
     t = util.O.gen_test_inputs(case.seed, case.prior, s, "oracle")
     t.round_to_half()
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    B = 2 * 16 * ncu                                    # the batch bench.py settles on (two tiles per CU)
+    B = tiles_per_cu * 16 * ncu                         # the batches bench.py settles on
     e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, B, s.N, impl=0, tanhEmbed=True, precision=16)
     info = e.kernelInfo(B, False)
-    assert info.split(" ")[0] == bench.HEADLINE_KERNEL, info
+    assert info.split(" ")[0] == bench.HEADLINE_KERNELS[tiles_per_cu], info
     e.setEmbeddings(t.embP, t.embC)
     for l in range(s.L):
         e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
@@ -648,11 +686,11 @@ def test_full_chip_batches_by_replication(B):
     e.close()
 
 
-@pytest.mark.parametrize("B,small_mode", [(4112, "wg"), (8208, "stream")])
+@pytest.mark.parametrize("B,small_mode", [(4112, "wg"), (8208, "wg"), (12304, "stream")])
 def test_full_chip_batches_by_replication_fp16(B, small_mode):
     """The same property for the fp16 production path (dump-free kernels, engine's own choice of
     organisation at full-chip batch sizes): the big batch must repeat, bit for bit, what the same
-    organisation generates for the 19 utterances alone (one tile per workgroup for 'wg': one and two
+    organisation generates for the 19 utterances alone (one tile per workgroup for 'wg': one, two and three
     tiles per workgroup perform the same arithmetic per utterance)."""
     case = cases.BY_NAME["R64S128A256_L7_B19_oddL"]
     s = case.shape
@@ -670,14 +708,14 @@ def test_full_chip_batches_by_replication_fp16(B, small_mode):
         e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
     e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
     e.setInputs(np.ascontiguousarray(t.Lh[:, :, idx, :]), np.ascontiguousarray(t.sel[:, idx]))
-    # the engine reports what it launches: dump-free kernels; two tiles per workgroup beyond one tile
-    # per CU, the loader/consumer kernel beyond two
+    # the engine reports what it launches: dump-free kernels; two / three tiles per workgroup beyond one / two tiles
+    # per CU, the loader/consumer kernel beyond three
     import torch
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     tiles = (B + 15) // 16
     info = e.kernelInfo(B, False)
     assert "DUMP=0" in info and "fp16" in info, info
-    want = "wavenet_stream" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
+    want = "wavenet_stream" if tiles > 3 * ncu else "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
     assert want in info, (info, ncu)
     y = np.full((B, s.N), -1, dtype=np.int32)
     assert e.run(s.N, B, y, 1, False)
