@@ -7,7 +7,7 @@ P=profiles
 BENCH="python bench.py --batch 8192 --samples 256 --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
 {
 echo "# round 2: $BENCH  under  rocprofv3 --kernel-trace --stats"
-echo "# (the default bench.py run settles on this batch itself: the largest that stays real time; bench.py's own line of this run:"
+echo "# (two tiles of 16 utterances per workgroup, 256 workgroups; bench.py's own line of this run:"
 echo "#  $(python - <<'PY'
 import json
 j = json.load(open("gpurun_out/prof2_bench_line.json"))
@@ -62,5 +62,44 @@ keep = [l for l in out.splitlines() if re.search(r"wavenet_wg|^#|^kernel", l)]
 open("profiles/r02_pmc_wg_b8192.txt", "w").write("\n".join(hdr + keep) + "\n")
 print("\n".join(hdr))
 PY
+# ---- three tiles per workgroup at 12288 utterances ----
+B3="python bench.py --batch 12288 --samples 128 --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
+{
+echo "# round 2: $B3  under  rocprofv3 --kernel-trace --stats"
+echo "# (three tiles of 16 utterances per workgroup, 256 workgroups: the launch shape of 8193 .. 12288 utterances per GPU; bench.py's own line of this run:"
+echo "#  $(python - <<'PY'
+import json
+j = json.load(open("gpurun_out/prof2_bench_line_b12288.json"))
+print("value %.1f M samples/s, kernel_ms %.3f (HIP events), khz_per_utterance %.2f, roofline.frac %.4f)" % (j["value"] / 1e6, j["roofline"]["kernel_ms"], j["khz_per_utterance"], j["roofline"]["frac"]))
+PY
+)"
+python scripts/prof_summary.py kernel gpurun_out/prof2_kt_b12288/p_results.db; } > $P/r02_kernel_trace_stats_wg_b12288.txt
+python - <<'PY'
+import json, subprocess, sys, re
+out = subprocess.run([sys.executable, "scripts/prof_summary.py", "pmc", "gpurun_out/prof2_fetch_b12288/p_results.db",
+                      "gpurun_out/prof2_write_b12288/p_results.db", "gpurun_out/prof2_sq_b12288/p_results.db"],
+                     capture_output=True, text=True).stdout
+v = {}
+for line in out.splitlines():
+    m = re.match(r"\S*wavenet_wg\S*\s+(\w+)\s+\d+\s+([\d.]+)", line)
+    if m:
+        v[m.group(1)] = float(m.group(2))
+f, w = v["FETCH_SIZE"], v["WRITE_SIZE"]
+hbm = (2 * f + w) * 1024
+alg = 12288 * 128 * (20 * 2 * 64 * 2 * 2 + 8)      # conditioning (2R) + ring read + ring write (R each), fp16, + selector + sample
+json.dump({"batch": 12288, "samples": 128, "fetch_size_kb": f, "write_size_kb": w, "hbm_bytes_per_launch": hbm,
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); "
+                   "separate --pmc passes; wn::wavenet_wg, three tiles per workgroup"},
+          open("profiles/traffic_r02_b12288.json", "w"), indent=1)
+hdr = ["# round 2, wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0> at batch 12288 x 128 samples (python bench.py --batch 12288 --samples 128 --steps 5 --warmup 1 --no-cpu-baseline --no-extras)",
+       "# separate runs: rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES",
+       "# HBM bytes per launch = (2*%.1f + %.1f) KB = %.2fe9 B  vs algorithmic %.2fe9 B: %.2fx" % (f, w, hbm / 1e9, alg / 1e9, hbm / alg),
+       "# SQ counters are per shader engine (32 of them): VALU : MFMA = %.2f, LDS bank-conflict cycles / LDS active cycles = %.1f %%" %
+       (v["SQ_INSTS_VALU"] / v["SQ_INSTS_MFMA"], 100 * v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"])]
+keep = [l for l in out.splitlines() if re.search(r"wavenet_wg|^#|^kernel", l)]
+open("profiles/r02_pmc_wg_b12288.txt", "w").write("\n".join(hdr + keep) + "\n")
+print("\n".join(hdr))
+PY
+cp gpurun_out/prof2_bench_line_b12288.json $P/r02_bench_line_under_rocprof_b12288.json
 cp gpurun_out/prof2_bench_line.json $P/r02_bench_line_under_rocprof.json
 ls -la $P

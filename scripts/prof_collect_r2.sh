@@ -14,6 +14,13 @@ run prof2_fetch --kernel-trace --pmc FETCH_SIZE
 run prof2_write --kernel-trace --pmc WRITE_SIZE
 run prof2_l2 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum
 run prof2_sq --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES
+# three tiles per workgroup (8193 .. 12288 utterances per GPU)
+CMD="python bench.py --batch 12288 --samples 128 --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
+run prof2_kt_b12288 --kernel-trace --stats
+run prof2_fetch_b12288 --kernel-trace --pmc FETCH_SIZE
+run prof2_write_b12288 --kernel-trace --pmc WRITE_SIZE
+run prof2_sq_b12288 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES
+grep -h "^{" gpurun_out/prof2_kt_b12288.log | tail -1 > gpurun_out/prof2_bench_line_b12288.json
 CMD="python scripts/nv_wavenet_perf.py -r 128 -s 256 -a 256 -l 30 -b 8 -m 3 -n 4096 -t 2048"
 run prof2_kt_c4 --kernel-trace --stats
 CMD="python scripts/nv_wavenet_perf.py -r 64 -s 256 -a 256 -l 20 -b 16 -m 3 -n 8192 -t 2048"
