@@ -460,19 +460,27 @@ def main():
                              "behind the generation of the previous chunk; Philox selectors; samples left in HBM",
                "sweep_khz": {}}
         best = None
-        for cand in sorted(set([B // 2, B * 3 // 4, B]), reverse=True):
+        for cand in sorted(set([B // 4, B * 3 // 8, B // 2, B * 3 // 4, B] + [c for c in (16 * ncu, 24 * ncu, 32 * ncu) if c <= B]),
+                           reverse=True):
             cand = max(16, cand // 64 * 64)
             k = end_to_end_khz(w, cand)
             e2e["sweep_khz"][str(cand)] = k
-            if k >= REALTIME_KHZ and best is None:
+            if k >= REALTIME_KHZ:
                 best = cand
+                break
         e2e["max_realtime_batch_per_gpu"] = best
         # ... and with no pack at all: the kernels read the caller's fp32 tensor in place (setConditioningDirect)
-        k_ip, info_ip = measure_khz(w, B, 128, in_place=True)
+        # (at the real-time batch of the packed path, then at two tiles / one tile per CU until it is real time)
+        ip_sweep = {}
+        for cand in [B] + [c for c in (32 * ncu, 16 * ncu) if c < B]:
+            k_ip, info_ip = measure_khz(w, cand, 128, in_place=True)
+            ip_sweep[str(cand)] = k_ip
+            if k_ip >= REALTIME_KHZ:
+                break
         e2e["in_place"] = {"definition": "conditioning fp32 [N][L][B][2R] in HBM read in place by the generation kernel "
                                          "(nvw_set_conditioning_direct): no packed copy, no second pass",
-                           "batch_per_gpu": B, "khz_per_utterance": k_ip, "kernel": info_ip.split(" ")[0],
-                           "real_time": bool(k_ip >= REALTIME_KHZ)}
+                           "batch_per_gpu": cand, "khz_per_utterance": k_ip, "kernel": info_ip.split(" ")[0],
+                           "real_time": bool(k_ip >= REALTIME_KHZ), "sweep_khz": ip_sweep}
 
     e = build_engine(w, B, N)
     kinfo = e.kernelInfo(B, False)
