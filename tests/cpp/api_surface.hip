@@ -47,6 +47,25 @@ static bool drive(int num_layers, int batch_size, int num_samples, int impl) {
     return ok && consumed == num_samples;
 }
 
+// The physical order of a wave's weight stream (wn::Cfg::streamPos: wavenet_wg's consumption order, shared by the
+// chain and the pipe through the same function) must be a permutation of the L * FLW layer fragments, start with the
+// current tap of layer 0 and end with the skip matrix of the last layer -- checked at compile time for a few depths.
+template <typename C> constexpr bool stream_layout_ok(int L) {
+    const int n = L * C::FLW;
+    for (int pos = 0; pos < n; pos++) {
+        int hits = 0;
+        for (int l = 0; l < L; l++)
+            for (int i = 0; i < C::FLW; i++) hits += C::streamPos(l, i, L) == (size_t)pos;
+        if (hits != 1) return false;
+    }
+    return C::streamPos(0, C::O_CUR, L) == 0 && C::streamPos(L - 1, C::O_SKIP + C::FW_SKIP - 1, L) == (size_t)n - 1 &&
+           C::streamPos(0, C::O_PREV, L) == (size_t)(L - 1) * C::FLW + C::FW_GATE + C::FW_RES;
+}
+static_assert(stream_layout_ok<wn::Cfg<true, 64, 256, 256, 1>>(2) && stream_layout_ok<wn::Cfg<true, 64, 256, 256, 3>>(3) &&
+                  stream_layout_ok<wn::Cfg<true, 64, 256, 256, 2>>(20) && stream_layout_ok<wn::Cfg<false, 32, 256, 256, 1>>(6) &&
+                  stream_layout_ok<wn::Cfg<true, 128, 256, 256, 1>>(7),
+              "Cfg::streamPos is not a permutation of the layer fragments");
+
 int main() {
     bool ok = drive<float, float, 64, 128, 256>(4, 4, 16, 1);      // the default R,S,A of the class template
     ok = drive<half2, half, 64, 128, 256>(4, 4, 16, 3) && ok;
