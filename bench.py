@@ -5,8 +5,12 @@ Metric (BASELINE.json): samples/sec/GPU and max real-time batch @24 kHz at R=64/
 20 layers, maxDilation 512, fp16.  One "step" = one run() launch of the hot path generating
 SAMPLES_PER_STEP samples for every utterance of the batch (synthetic conditioning / selectors /
 random-init weights already resident in HBM).  `value` = utterances x samples / second over all
-GPUs, measured at the largest batch whose per-utterance rate stays >= 24 kHz (found by a bounded
-bisection over the number of 16-utterance tiles before the timed region; override with --batch).
+GPUs, measured at the largest batch whose per-utterance rate stays >= 24 kHz AT STEADY STATE: the
+reference times N = 16 384 samples with maxDilation 512 (nv_wavenet_perf.cu:195-199), where every
+dilated tap is live and every ring has wrapped, so a batch counts as real time only if samples
+640 .. 1151 of an utterance (all d = 512 taps live) are generated at >= 24 kHz (`steady_state`; found
+by a bounded bisection over the number of 16-utterance tiles before the timed region; override with
+--batch), and the timed steps themselves continue one long utterance from sample 640 on.
 
 Beside it (rank 0, N = 1 only) the reference's own measurement is reproduced for the BASELINE configs
 C2 / C3 / C4 (`reference_definition`): nv_wavenet_perf.cu:67-87 -- 16 384 samples through run_chunks in
@@ -67,36 +71,37 @@ HEAD = C3                                     # the shape the headline metric is
 R, S, A, L, MAXD = HEAD.R, HEAD.S, HEAD.A, HEAD.L, HEAD.maxD
 # the device code the engine launches for the headline point (asserted against nvw_kernel_info, and pinned
 # by tests/test_parity_gpu.py::test_benchmarked_launch_*: the timed kernel is the parity-tested one)
-HEADLINE_KERNELS = {2: "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=1,DUMP=0>",     # by tiles per workgroup
-                    3: "wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0>"}
+HEADLINE_KERNELS = {2: "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=1,DUMP=0,RAW=0>",     # by tiles per workgroup
+                    3: "wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0,RAW=0>"}
 HEADLINE_KERNEL = HEADLINE_KERNELS[2]
 
 
-def lds_bytes_per_sample(stream_mode, bt=1):
+def lds_bytes_per_sample(bt=1):
     """Algorithmic LDS bytes moved per generated sample per WORKGROUP (C3 shape, fp16).
     wg kernel (4 waves on bt tiles): per layer every wave reads the x, x[t-d] and h fragment images
     (R/32 KiB each) and its bias quads, and writes its quarter of h, x and the dilated tap; the head
-    moves skip / zs images (S/32, A/32 KiB, read by all 4 waves) and the fp32 logits once each way.
-    stream kernel (4 consumer waves, one tile each): the whole weight stream is written to LDS once
-    by LDS-DMA and read once by every consumer; activations never leave registers."""
+    moves skip / zs images (S/32, A/32 KiB, read by all 4 waves) and the fp32 logits once each way."""
     kf = lambda n: n // 32 * 1024
-    if stream_mode:
-        return 5 * HEAD.weight_bytes + 4 * (16 * A * 4 * 2)
     per_layer = bt * (4 * 3 * kf(R) + 3 * kf(R)) + 4 * 64 * 16 * 3        # exchanges + bias quads
     head = bt * (5 * kf(S) + 5 * kf(A) + 2 * 16 * A * 4 + 2 * kf(R)) + 4 * 64 * 16 * (S // 64 + 2 * A // 64)
     return L * per_layer + head
 
 
+COND_STD = 0.5                                # conditioning: uniform with this standard deviation
+
+
 def make_weights(sh=HEAD, seed=3):
-    """The parity recipe of nv_wavenet_test.cu:36-111: uniform +-0.25/R for embeddings, output head;
-    +-0.25/rows for per-layer matrices and biases."""
+    """Random-init weights at the magnitudes of a trained network (uniform draws, fan-in scaled like the parity tests'
+    O(1) recipe, tests/util.py:o1_recipe): activations and logits of order one in every layer, all 256 bins in play --
+    under the reference's +-0.25/rows recipe (nv_wavenet_test.cu:36-111) the logits are a constant and the output a
+    uniform distribution whatever the network computes."""
     rng = np.random.default_rng(seed)
     R, S, A, L = sh.R, sh.S, sh.A, sh.L
-    u = lambda sc, *s: ((rng.random(s, dtype=np.float32) - 0.5) * sc).astype(np.float32)
-    w = dict(embP=u(0.5 / R, A, R), embC=u(0.5 / R, A, R),
-             Wprev=u(0.25 / R, L, R, 2 * R), Wcur=u(0.25 / R, L, R, 2 * R), Bh=u(0.25 / R, L, 2 * R),
-             Wres=u(0.5 / R, L, R, R), Bres=u(0.5 / R, L, R), Wskip=u(0.5 / S, L, R, S), Bskip=u(0.5 / S, L, S),
-             Wzs=u(0.5 / R, S, A), Bzs=u(0.5 / R, A), Wza=u(0.5 / R, A, A), Bza=u(0.5 / R, A))
+    u = lambda std, *s: ((rng.random(s, dtype=np.float32) - 0.5) * (std * np.sqrt(12.0))).astype(np.float32)
+    w = dict(embP=u(0.45, A, R), embC=u(0.45, A, R),
+             Wprev=u(0.55 / np.sqrt(R), L, R, 2 * R), Wcur=u(0.55 / np.sqrt(R), L, R, 2 * R), Bh=u(0.3, L, 2 * R),
+             Wres=u(0.5 / np.sqrt(R), L, R, R), Bres=u(0.05, L, R), Wskip=u(1.5 / np.sqrt(R * L), L, R, S), Bskip=u(0.3 / np.sqrt(L), L, S),
+             Wzs=u(1.6 / np.sqrt(S), S, A), Bzs=u(0.2, A), Wza=u(1.5 / np.sqrt(A), A, A), Bza=u(0.2, A))
     return w
 
 
@@ -113,36 +118,33 @@ def build_engine(w, B, N, sh=HEAD, precision=16, impl=0, organisation=0):
 
 
 def device_inputs(B, N, seed, sh=HEAD):
-    """Synthetic conditioning [N][L][B][2R] (uniform +-0.25/R) and selectors [N][B] in HBM."""
+    """Synthetic conditioning [N][L][B][2R] (uniform, standard deviation COND_STD) and selectors [N][B] in HBM."""
     import torch
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
     Lh = torch.empty(N, sh.L, B, 2 * sh.R, dtype=torch.float32, device="cuda")
-    Lh.uniform_(-0.25 / sh.R, 0.25 / sh.R, generator=g)
+    hw = COND_STD * 3.0 ** 0.5
+    Lh.uniform_(-hw, hw, generator=g)
     sel = torch.rand(N, B, dtype=torch.float32, device="cuda", generator=g)
     return Lh, sel
 
 
 def samples_per_step_for(B):
-    # keep the fp32 source of the conditioning under ~24 GB
-    per_sample = L * B * 2 * R * 4
-    n = int(24e9 // per_sample)
+    # keep the packed conditioning of STEADY_FROM + n samples under ~60 GB
+    per_sample = L * B * 2 * R * 2
+    n = int(60e9 // per_sample) - STEADY_FROM
     n = max(64, min(2048, n // 64 * 64))
     return n
 
 
-def measure_khz(w, B, N, seed=11, organisation=0, in_place=False):
-    """per-utterance kHz of one launch at batch B with pre-packed conditioning (HIP events on the launch
-    stream), or with the conditioning read in place from the fp32 tensor (in_place).
-    organisation: 0 = the engine's own choice, else a forced nvwOrganisation."""
+def measure_khz(w, B, N, seed=11, organisation=0):
+    """per-utterance kHz of one launch of N samples FROM SAMPLE 0 at batch B with pre-packed conditioning (HIP events on
+    the launch stream).  organisation: 0 = the engine's own choice, else a forced nvwOrganisation."""
     import torch
     e = build_engine(w, B, N, organisation=organisation)
     Lh, sel = device_inputs(B, N, seed)
     e.setInputs(Lh, sel)
-    if in_place:
-        e.setConditioningDirect(Lh)
-    else:
-        del Lh
+    del Lh
     torch.cuda.synchronize()
     e.time_runs(1, min(N, 64), B)
     ms = e.time_runs(1, N, B)
@@ -150,6 +152,68 @@ def measure_khz(w, B, N, seed=11, organisation=0, in_place=False):
     e.close()
     torch.cuda.empty_cache()
     return N / ms, info
+
+
+# ---- steady state ----------------------------------------------------------------------------------------------------
+# The reference's figure is N = 16 384 samples with maxDilation 512 (nv_wavenet_perf.cu:67-87,195-199): after the first
+# 512 samples every dilated tap is live and every ring has wrapped.  A launch restarted at t = 0 never loads the taps with
+# d >= its length.  So: an engine of capacity STEADY_FROM + n, conditioning for all of it, samples 0 .. STEADY_FROM-1
+# generated untimed, and what is timed is samples STEADY_FROM .. STEADY_FROM+n-1.
+STEADY_FROM = 640
+COND_BLOCK = 64                               # samples per reused fp32 source block of synthetic conditioning
+
+
+def steady_engine(w, B, n_timed, seed=11, in_place=None, organisation=0):
+    """Engine at batch B with samples 0 .. STEADY_FROM-1 behind it.  in_place: None = conditioning packed (chunk-wise from
+    one reused COND_BLOCK-sample fp32 block: the packed copy of STEADY_FROM + n_timed samples is what stays in HBM, 5 120 B
+    per utterance and sample), or torch.float32 / torch.float16 = a full [N][L][B][2R] tensor of that type consumed in
+    place.  Returns (engine, total samples, keep-alive)."""
+    import torch
+    N = STEADY_FROM + n_timed
+    e = build_engine(w, B, N, organisation=organisation)
+    block, _ = device_inputs(B, COND_BLOCK, seed)
+    e.setSelectorSeed(seed)
+    keep = None
+    if in_place is None:
+        e.resetHistory()
+        for first in range(0, N, COND_BLOCK):
+            e.packConditioning(block[:min(COND_BLOCK, N - first)], first, min(COND_BLOCK, N - first))
+    else:
+        keep = torch.empty(N, L, B, 2 * R, dtype=in_place, device="cuda")
+        for first in range(0, N, COND_BLOCK):
+            keep[first:first + COND_BLOCK].copy_(block[:min(COND_BLOCK, N - first)])
+        e.setConditioningDirect(keep)
+    del block
+    torch.cuda.synchronize()
+    assert e.run_partial_chunk(0, STEADY_FROM, N, B)
+    e.synchronize()
+    return e, N, keep
+
+
+def time_range(e, first, count, N, B, reps=1):
+    """HIP-event milliseconds per launch of samples [first, first + count) on torch's current stream"""
+    import torch
+    st = torch.cuda.current_stream()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(st)
+    for _ in range(reps):
+        assert e.run_partial_chunk(first, count, N, B, st.cuda_stream)
+    b.record(st)
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def measure_steady_khz(w, B, n_timed=512, seed=11, in_place=None, organisation=0):
+    """per-utterance kHz over samples STEADY_FROM .. STEADY_FROM + n_timed - 1 (all taps live, all rings wrapped)"""
+    import torch
+    e, N, keep = steady_engine(w, B, n_timed, seed, in_place, organisation)
+    ms = time_range(e, STEADY_FROM, n_timed, N, B)
+    info = e.kernelInfo(B, False)
+    ok = e.chainStatus() == 0
+    e.close()
+    del keep
+    torch.cuda.empty_cache()
+    return (n_timed / ms) if ok else 0.0, info
 
 
 def reference_definition_khz(sh, impl, N=16384, chunk=2048):
@@ -187,7 +251,7 @@ def end_to_end_khz(w, B, chunk=256, chunks=4, seed=21):
     e = build_engine(w, B, N)
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
-    blocks = [torch.empty(chunk, L, B, 2 * R, dtype=torch.float32, device="cuda").uniform_(-0.25 / R, 0.25 / R, generator=g)
+    blocks = [torch.empty(chunk, L, B, 2 * R, dtype=torch.float32, device="cuda").uniform_(-COND_STD * 3.0 ** 0.5, COND_STD * 3.0 ** 0.5, generator=g)
               for _ in range(2)]                       # two source buffers, refilled round-robin (synthetic)
     sel = torch.rand(N, B, dtype=torch.float32, device="cuda", generator=g)
     e.setSelectorSeed(seed)
@@ -238,7 +302,7 @@ def cpu_run_once(w, n, B=16, seed=5):
     t = T()
     for k, v in w.items():
         setattr(t, k, v)
-    Lh = ((rng.random((n, L, B, 2 * R), dtype=np.float32) - 0.5) * (0.5 / R)).astype(np.float32)
+    Lh = ((rng.random((n, L, B, 2 * R), dtype=np.float32) - 0.5) * (COND_STD * np.sqrt(12.0))).astype(np.float32)
     sel = rng.random((n, B), dtype=np.float32) * 0.999
     o = cls(L, B, n, R, S, A, MAXD)
     o.set_model(t)
@@ -362,7 +426,7 @@ def main():
     ap.add_argument("--config", default="headline", choices=["headline", "c5"],
                     help="c5: BASELINE configs[4], global batch 64 sharded over the ranks (8 x 8 on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip reference_definition / end_to_end / throughput_mode")
+    ap.add_argument("--no-extras", action="store_true", help="skip reference_definition / end_to_end / oversubscribed")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
     ap.add_argument("--selftest-dist", action="store_true", help="launcher / rendezvous / gather plumbing only (no GPU)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
@@ -416,9 +480,10 @@ def main():
         if rank == 0:
             c3_b16_khz, _ = measure_khz(w, 16, 1024)
             sweep[16] = c3_b16_khz
+            # every probe is a steady-state one: samples 640 .. 1151 of an utterance (measure_steady_khz)
             lo, hi = 1, None                      # in tiles of 16 utterances: lo is real time, hi is not
-            for tiles in (ncu, 2 * ncu, 4 * ncu):
-                khz, _ = measure_khz(w, 16 * tiles, 128)
+            for tiles in (ncu, 2 * ncu, 3 * ncu, 4 * ncu):
+                khz, _ = measure_steady_khz(w, 16 * tiles)
                 sweep[16 * tiles] = khz
                 if khz >= REALTIME_KHZ:
                     lo = tiles
@@ -429,7 +494,7 @@ def main():
                 mid = (lo + hi) // 2 // 4 * 4
                 if mid <= lo:
                     break
-                khz, _ = measure_khz(w, 16 * mid, 128)
+                khz, _ = measure_steady_khz(w, 16 * mid)
                 sweep[16 * mid] = khz
                 if khz >= REALTIME_KHZ:
                     lo = mid
@@ -441,7 +506,7 @@ def main():
                 choice = choice.cpu()
             dist.broadcast(choice, 0)
         B = int(choice.item())
-    N = args.samples or (2048 if args.config == "c5" else samples_per_step_for(B))
+    N = args.samples or (2048 if args.config == "c5" else samples_per_step_for(B))      # samples per step
 
     # ---- beside the headline (rank 0, one GPU): the reference's own measurement on C2 / C3 / C4, the
     #      throughput organisation, and the real-time batch with conditioning streamed per chunk ----
@@ -452,10 +517,10 @@ def main():
             refdef[sh.name] = {"single_workgroup": reference_definition_khz(sh, 1),
                                "multi_cu_chain": reference_definition_khz(sh, 3),
                                "auto": reference_definition_khz(sh, 0)}
-        bt = 64 * ncu
-        khz_t, info_t = (sweep.get(bt), None) if sweep.get(bt) else measure_khz(w, bt, 128, organisation=4)
+        bt = 64 * ncu                                 # four tiles per CU: more workgroups than CUs, not real time
+        khz_t = sweep.get(bt) or measure_steady_khz(w, bt)[0]
         thr = {"batch_per_gpu": bt, "khz_per_utterance": khz_t, "samples_per_sec_per_gpu": bt * khz_t * 1e3,
-               "kernel": "wn::wavenet_stream", "real_time": bool(khz_t >= REALTIME_KHZ)}
+               "kernel": HEADLINE_KERNELS[3], "real_time": bool(khz_t >= REALTIME_KHZ)}
         e2e = {"definition": "conditioning fp32 [N][L][B][2R] in HBM, packed per chunk of 256 samples on a second stream "
                              "behind the generation of the previous chunk; Philox selectors; samples left in HBM",
                "sweep_khz": {}}
@@ -469,26 +534,28 @@ def main():
                 best = cand
                 break
         e2e["max_realtime_batch_per_gpu"] = best
-        # ... and with no pack at all: the kernels read the caller's fp32 tensor in place (setConditioningDirect)
-        # (at the real-time batch of the packed path, then at two tiles / one tile per CU until it is real time)
-        ip_sweep = {}
-        for cand in [B] + [c for c in (32 * ncu, 16 * ncu) if c < B]:
-            k_ip, info_ip = measure_khz(w, cand, 128, in_place=True)
-            ip_sweep[str(cand)] = k_ip
-            if k_ip >= REALTIME_KHZ:
-                break
-        e2e["in_place"] = {"definition": "conditioning fp32 [N][L][B][2R] in HBM read in place by the generation kernel "
-                                         "(nvw_set_conditioning_direct): no packed copy, no second pass",
-                           "batch_per_gpu": cand, "khz_per_utterance": k_ip, "kernel": info_ip.split(" ")[0],
-                           "real_time": bool(k_ip >= REALTIME_KHZ), "sweep_khz": ip_sweep}
+        # ... and with no pack at all: the kernels read the caller's tensor in place (setConditioningDirect), fp16 (the
+        # engine's T_data) or fp32; steady state like the headline, at the headline batch, then at two / one tile per CU
+        # until it is real time
+        e2e["in_place"] = {}
+        for name, dt in (("fp16_tensor", torch.float16), ("fp32_tensor", torch.float32)):
+            ip_sweep = {}
+            for cand in [B] + [c for c in (32 * ncu, 16 * ncu) if c < B]:
+                k_ip, info_ip = measure_steady_khz(w, cand, in_place=dt)
+                ip_sweep[str(cand)] = k_ip
+                if k_ip >= REALTIME_KHZ:
+                    break
+            e2e["in_place"][name] = {"definition": "conditioning %s [N][L][B][2R] in HBM read in place by the generation kernel "
+                                                   "(nvw_set_conditioning_direct_t): no packed copy, no second pass; samples 640..1151" % name,
+                                     "batch_per_gpu": cand, "khz_per_utterance": k_ip, "kernel": info_ip.split(" ")[0],
+                                     "real_time": bool(k_ip >= REALTIME_KHZ), "sweep_khz": ip_sweep}
 
-    e = build_engine(w, B, N)
+    # ---- the timed workload: every step generates samples STEADY_FROM .. STEADY_FROM+N-1 (all dilated taps live, all rings
+    #      wrapped, conditioning rows of exactly those samples) for every utterance, from the state the previous step left
+    e, NTOT, _keep = steady_engine(w, B, N, 100 + rank)
     kinfo = e.kernelInfo(B, False)
-    Lh, sel = device_inputs(B, N, 100 + rank)
-    e.setInputs(Lh, sel)
-    del Lh, sel
     torch.cuda.empty_cache()
-    ybuf = [torch.zeros(B, N, dtype=torch.int32, device="cuda") for _ in range(2)]
+    ybuf = [torch.zeros(B, NTOT, dtype=torch.int32, device="cuda") for _ in range(2)]
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
     gathered_rows = [0]
@@ -504,11 +571,12 @@ def main():
             gathered_rows[0] = pending.pop(0)().shape[0]
         if events is not None:
             events[0].record(stream)
-        assert e.run(N, B, y, 1, False, sptr)
+        assert e.run_partial_chunk(STEADY_FROM, N, NTOT, B, sptr)
         if events is not None:
             events[1].record(stream)
+        e.getYOut(y, STEADY_FROM, N, sptr)               # the step's samples, device to device
         if world > 1:
-            _, fin = gather_samples(y, total_batch, async_op=True)
+            _, fin = gather_samples(y[:, STEADY_FROM:].contiguous(), total_batch, async_op=True)
             pending.append(fin)
 
     for i in range(args.warmup):
@@ -535,7 +603,7 @@ def main():
         dt = float(tt.item())
         assert gathered_rows[0] == total_batch, "the gather returned %d rows, expected %d" % (gathered_rows[0], total_batch)
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
-    ylast = ybuf[(args.steps - 1) % 2]
+    ylast = ybuf[(args.steps - 1) % 2][:, STEADY_FROM:]
     hist = int(torch.unique(ylast).numel())
     status = e.chainStatus()
     e.close()
@@ -549,13 +617,12 @@ def main():
         flops = units * HEAD.flops
         tiles = (B + 15) // 16
         kname = kinfo.split(" ")[0]                             # what the engine reports it launches
-        stream_mode = "wavenet_stream" in kname
         chain_mode = "wavenet_chain" in kname
         bt = 3 if "BT=3" in kname else 2 if "BT=2" in kname else 1
-        if not args.batch and args.config == "headline" and tiles > ncu and not stream_mode:
+        if not args.batch and args.config == "headline" and tiles > ncu:
             assert kname == HEADLINE_KERNELS[bt], kinfo     # the launches the parity tests pin
         # workgroups (weight-stream passes) per sample
-        passes = (tiles + 3) // 4 if stream_mode else (tiles + bt - 1) // bt
+        passes = (tiles + bt - 1) // bt
         traffic = None
         # HBM bytes per launch from the PMC passes of the latest profiled round (profiles/traffic_rNN.json,
         # written by scripts/make_profiles.sh); only valid for the launch shape it was measured on
@@ -578,28 +645,33 @@ def main():
             roofline["l2_weight_stream"] = dict(achieved=passes * N * HEAD.weight_bytes / (kern_ms * 1e-3) / 1e9,
                                                 peak=L2_PEAK_GBS, unit="GB/s")
             roofline["l2_weight_stream"]["frac"] = roofline["l2_weight_stream"]["achieved"] / L2_PEAK_GBS
-            roofline["lds"] = dict(achieved=passes * N * lds_bytes_per_sample(stream_mode, 1 if stream_mode else bt) / (kern_ms * 1e-3) / 1e9,
-                                   peak=LDS_PEAK_GBS, unit="GB/s")
+            roofline["lds"] = dict(achieved=passes * N * lds_bytes_per_sample(bt) / (kern_ms * 1e-3) / 1e9,
+                                   peak=LDS_PEAK_GBS, unit="GB/s", source="algorithmic bytes (exchange images, bias quads, logits); "
+                                   "counter-based figure: profiles/r03_pmc_lds_*.txt")
             roofline["lds"]["frac"] = roofline["lds"]["achieved"] / LDS_PEAK_GBS
         out = {
             "metric": "samples/sec (all GPUs) at the max real-time batch @24kHz, R64/S256/A256 20L fp16",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.config == "c5" else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "C3: R=64 S=256 A=256 L=20 maxDilation=512 fp16, autoregressive generation"
+            "config": {"workload": "C3: R=64 S=256 A=256 L=20 maxDilation=512 fp16, autoregressive generation at steady state "
+                                   "(each step = samples %d..%d of every utterance: all dilated taps live, all rings wrapped)" % (STEADY_FROM, STEADY_FROM + N - 1)
                        if args.config == "headline" else
                        "C5: C3 shape, global batch 64 sharded over the ranks, RCCL gather of the samples",
                        "batch_per_gpu": B, "global_batch": total_batch, "samples_per_step": N,
                        "parallelism": "batch-sharded x%d, final RCCL all_gather" % world},
             "samples_per_sec_per_gpu": value / world,
             "khz_per_utterance": khz, "max_realtime_batch_per_gpu": B if khz >= REALTIME_KHZ else None,
-            "max_realtime_batch_definition": "conditioning pre-packed in HBM (setInputs outside the timed region, like the "
-                                             "reference's harness); see end_to_end for conditioning streamed per chunk",
+            "max_realtime_batch_definition": "largest batch whose samples 640..1151 (steady state: nv_wavenet_perf.cu:195-199 times "
+                                             "N=16384 at maxDilation 512) are generated at >= 24 kHz per utterance; conditioning pre-packed in HBM "
+                                             "(setInputs outside the timed region, like the reference's harness); see end_to_end for "
+                                             "conditioning streamed per chunk or read in place",
+            "realtime_margin": khz / REALTIME_KHZ - 1.0,
             "realtime_sweep_khz": {str(k): v for k, v in sorted(sweep.items())},
             "c3_b16": {"khz_per_utterance": c3_b16_khz, "samples_per_sec": None if c3_b16_khz is None else 16e3 * c3_b16_khz},
             "reference_definition": refdef,
             "end_to_end": e2e,
-            "throughput_mode": thr,
+            "oversubscribed": thr,
             "distinct_samples_in_last_step": hist,
             "roofline": roofline,
         }

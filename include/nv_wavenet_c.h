@@ -27,6 +27,8 @@
 #ifndef NV_WAVENET_C_H
 #define NV_WAVENET_C_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -44,10 +46,9 @@ nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int m
                        int batch_size, int num_samples, int implementation, int tanh_embed);
 /* The same with an explicit kernel organisation (the last, optional argument of this repo's nvWavenetInfer
  * constructor; 0 = from `implementation` and the batch size like nvw_create):
- *   1 wavenet_wg (1 or 2 tiles of 16 utterances per workgroup by batch size)   2 / 3 wavenet_wg with exactly 1 / 2
- *   4 wavenet_stream (loader / consumer waves)   5 wavenet_chain (multi-CU, resident weights, fewest CUs)
- *   6 wavenet_chain with one layer per CU   7 wavenet_pipe (the chain kept full: groups of tiles in flight, large batches)
- *   8 wavenet_wg with 3 tiles per workgroup (fp16, R <= 64; two tiles otherwise).
+ *   1 wavenet_wg (1, 2 or 3 tiles of 16 utterances per workgroup by batch size)   2 / 3 / 4 wavenet_wg with exactly 1 / 2 / 3
+ *   (three: fp16, R <= 64; two tiles otherwise)   5 wavenet_chain (multi-CU, resident weights, fewest CUs)
+ *   6 wavenet_chain with one layer per CU.
  * Returns NULL when the shape does not fit a CU in that organisation (the reference's variants print
  * and return false for shapes they do not support, nv_wavenet_singleblock.cuh:273-286). */
 nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, int max_dilation,
@@ -84,11 +85,22 @@ void nvw_pack_conditioning(nvw_engine* e, float* Lh, int first_sample, int count
  * the caller and kept alive and unchanged until the run calls that follow have completed.  Resets the history like
  * nvw_set_inputs; pair with nvw_set_selector_seed.  Same samples as the packed path, bit for bit. */
 void nvw_set_conditioning_direct(nvw_engine* e, float* Lh, int num_samples);
+/* The same for a tensor of `precision` bits per element: 32 (float) or -- fp16 engines only -- 16 (IEEE half, the engine's
+ * T_data: the reference keeps its conditioning in T_data, nv_wavenet.cuh:326; half the bytes of the fp32 tensor).  Returns 0
+ * (and changes nothing) when the engine cannot read that element type in place. */
+int nvw_set_conditioning_direct_t(nvw_engine* e, const void* Lh, int num_samples, int precision);
 /* the selector half of nvw_set_inputs ([num_samples][batch] uniform draws, host or device); conditioning and history untouched */
 void nvw_set_selectors(nvw_engine* e, float* output_selectors, int num_samples);
-/* 0 when every multi-CU (wavenet_chain) launch so far ran to completion, else the code of the first
- * hand-off that timed out; synchronises the device */
+/* Multi-CU (wavenet_chain) launches need all their workgroups resident at once; when other work holds CUs a launch gives up
+ * after a bounded wait and the engine re-runs its samples on wavenet_wg from the state the launch started with, in stream
+ * order, so the samples delivered are the right ones either way.  nvw_chain_status: 0, or the code of a give-up that could
+ * not be repaired; nvw_chain_fallbacks: launches that were re-run; nvw_chain_last_timeout: code of the latest of those
+ * (0x100+stage x hand-off, 0x200+stage skip sums, 0x300 head, 0x400+ placement exchange).  All three synchronise the device.
+ * nvw_set_chain_timeout_ms: the bound of every hand-off wait (default 1500 ms). */
 unsigned nvw_chain_status(nvw_engine* e);
+unsigned nvw_chain_fallbacks(nvw_engine* e);
+unsigned nvw_chain_last_timeout(nvw_engine* e);
+void nvw_set_chain_timeout_ms(nvw_engine* e, double ms);
 /* Samples [init_sample, init_sample + count) of a num_samples-long utterance, asynchronously on `stream`
  * (one chunk of run_chunks, for hosts that drive the chunks themselves); nvw_reset_history puts the
  * sample history back to 128 like nvw_set_inputs does, without touching the conditioning. */
@@ -96,6 +108,8 @@ int nvw_run_range(nvw_engine* e, int init_sample, int count, int num_samples, in
 void nvw_reset_history(nvw_engine* e, void* stream);
 void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed);
 void nvw_set_audio_out(nvw_engine* e, short* pcm_out);
+/* the same with the buffer's size in int16 values stated: every run call then checks batch * num_samples <= elems */
+void nvw_set_audio_out_n(nvw_engine* e, short* pcm_out, size_t elems);
 /* Introspection: the device code nvw_run(e, n, batch_size, ..., dump_activations, ...) launches, e.g.
  * "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=1,DUMP=0> tiles/wg=2 wgs=256 lds=149120" */
 void nvw_kernel_info(nvw_engine* e, int batch_size, int dump_activations, char* buf, int buf_size);

@@ -37,12 +37,17 @@ SIGNATURES = {
     "nvw_set_conditioning_n": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_pack_conditioning": (None, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_void_p]),
     "nvw_set_conditioning_direct": (None, [C.c_void_p, _fp, C.c_int]),
+    "nvw_set_conditioning_direct_t": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "nvw_set_selectors": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_chain_status": (C.c_uint, [C.c_void_p]),
+    "nvw_chain_fallbacks": (C.c_uint, [C.c_void_p]),
+    "nvw_chain_last_timeout": (C.c_uint, [C.c_void_p]),
+    "nvw_set_chain_timeout_ms": (None, [C.c_void_p, C.c_double]),
     "nvw_run_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "nvw_reset_history": (None, [C.c_void_p, C.c_void_p]),
     "nvw_set_selector_seed": (None, [C.c_void_p, C.c_ulonglong]),
     "nvw_set_audio_out": (None, [C.c_void_p, C.c_void_p]),
+    "nvw_set_audio_out_n": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "nvw_kernel_info": (None, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "nvw_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_void_p]),
     "nvw_run_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_void_p]),

@@ -13,15 +13,19 @@ struct nvw_engine {
     virtual void setInputs(float*, float*, int) = 0;
     virtual void setConditioning(float*, int) = 0;
     virtual void packConditioning(float*, int, int, hipStream_t) = 0;
-    virtual void setConditioningDirect(float*, int) = 0;
+    virtual void setConditioningDirect(const void*, int, int) = 0;
     virtual void setSelectors(float*, int) = 0;
     virtual bool run_range(int, int, int, int, hipStream_t) = 0;
     virtual void resetHistory(hipStream_t) = 0;
     virtual bool supported() = 0;
     virtual unsigned chainStatus() = 0;
+    virtual unsigned chainFallbacks() = 0;
+    virtual unsigned chainLastTimeout() = 0;
+    virtual void setChainTimeoutMs(double) = 0;
+    virtual int precisionBits() = 0;
     virtual int maxSamples() = 0;
     virtual void setSelectorSeed(unsigned long long) = 0;
-    virtual void setAudioOut(short*) = 0;
+    virtual void setAudioOut(short*, size_t) = 0;
     virtual void kernelInfo(int, bool, char*, int) = 0;
     virtual bool run(int, int, int*, int, bool, hipStream_t) = 0;
     virtual bool run_partial(int, int, int, int*, int, bool, hipStream_t) = 0;
@@ -47,15 +51,19 @@ struct EngineImpl : nvw_engine {
     void setInputs(float* Lh, float* sel, int n) override { eng.setInputs(Lh, sel, n); }
     void setConditioning(float* Lh, int n) override { eng.setConditioning(Lh, n); }
     void packConditioning(float* Lh, int first, int count, hipStream_t s) override { eng.packConditioning(Lh, first, count, s); }
-    void setConditioningDirect(float* Lh, int n) override { eng.setConditioningDirect(Lh, n); }
+    void setConditioningDirect(const void* Lh, int n, int prec) override { eng.setConditioningDirect(Lh, n, prec); }
     void setSelectors(float* sel, int n) override { eng.setSelectors(sel, n); }
     bool run_range(int i, int c, int n, int b, hipStream_t s) override { return eng.run_range(i, c, n, b, s); }
     void resetHistory(hipStream_t s) override { eng.resetHistory(s); }
     bool supported() override { return eng.supported(); }
     unsigned chainStatus() override { return eng.chainStatus(); }
+    unsigned chainFallbacks() override { return eng.chainFallbacks(); }
+    unsigned chainLastTimeout() override { return eng.chainLastTimeout(); }
+    void setChainTimeoutMs(double ms) override { eng.setChainTimeoutMs(ms); }
+    int precisionBits() override { return std::is_same<Td, float>::value ? 32 : 16; }
     int maxSamples() override { return cap; }
     void setSelectorSeed(unsigned long long seed) override { eng.setSelectorSeed(seed); }
-    void setAudioOut(short* pcm) override { eng.setAudioOut(pcm); }
+    void setAudioOut(short* pcm, size_t n) override { eng.setAudioOut(pcm, n); }
     void kernelInfo(int b, bool dump, char* buf, int n) override { eng.kernelInfo(b, dump, buf, n); }
     bool run(int n, int b, int* y, int bspb, bool dump, hipStream_t s) override {
         return eng.run(n, b, y, bspb, dump, s);

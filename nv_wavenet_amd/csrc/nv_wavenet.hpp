@@ -11,8 +11,8 @@
 // What is different underneath.  `Implementation` selects between device-code ORGANISATIONS of the
 // same MFMA engine (all parity-tested against each other and the oracle):
 //   SINGLE_BLOCK            one workgroup runs the whole network for its utterance tile(s), weights
-//                           streamed from L2 every sample: wn::wavenet_wg (1 or 2 tiles of 16 utterances
-//                           per workgroup) or, beyond two tiles per CU, wn::wavenet_stream
+//                           streamed from L2 every sample: wn::wavenet_wg with 1, 2 or 3 tiles of 16
+//                           utterances per workgroup by batch size
 //   DUAL_BLOCK, PERSISTENT  wn::wavenet_chain: the layer stack split over a chain of CUs, each holding
 //                           its layers' weights resident in registers + LDS, plus a head CU; hand-offs
 //                           through L2-visible tagged granules (wn_chain.hpp); fewest CUs that hold the model
@@ -37,8 +37,6 @@
 
 #include "wn_chain.hpp"
 #include "wn_kernels.hpp"
-#include "wn_pipe.hpp"
-#include "wn_stream.hpp"
 
 #ifndef gpuErrChk
 #define gpuErrChk(ans) { wnGpuAssert((ans), __FILE__, __LINE__); }
@@ -53,14 +51,13 @@ inline void wnGpuAssert(hipError_t code, const char* file, int line, bool abort 
 // kernel organisations (beyond the reference: its Implementation enum maps onto these, see above)
 enum nvwOrganisation {
     NVW_ORG_AUTO = 0,     // from Implementation and the batch size
-    NVW_ORG_WG = 1,       // wn::wavenet_wg, 1 or 2 tiles per workgroup by batch size
+    NVW_ORG_WG = 1,       // wn::wavenet_wg, 1, 2 or 3 tiles per workgroup by batch size
     NVW_ORG_WG1 = 2,      // wn::wavenet_wg, one tile per workgroup
     NVW_ORG_WG2 = 3,      // wn::wavenet_wg, two tiles per workgroup
-    NVW_ORG_STREAM = 4,   // wn::wavenet_stream (loader / consumer waves, 4 tiles per workgroup)
+    NVW_ORG_WG3 = 4,      // wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64; else two)
     NVW_ORG_CHAIN = 5,    // wn::wavenet_chain, as many layers per CU as stay resident
     NVW_ORG_CHAIN1 = 6,   // wn::wavenet_chain, one layer per CU
-    NVW_ORG_PIPE = 7,     // wn::wavenet_pipe: the chain kept full (groups of tiles in flight per chain), large batches
-    NVW_ORG_WG3 = 8       // wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64)
+    NVW_ORG_LAST = NVW_ORG_CHAIN1
 };
 
 template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
@@ -76,19 +73,14 @@ public:
 
 protected:
     using C = wn::Cfg<F16, R, S, A, 1>;   // stream / layout constants do not depend on BT
-    using SC = wn::SCfg<F16, R, S, A>;     // throughput (loader/consumer) kernel
     using CC = wn::CCfg<F16, R, S, A>;     // multi-CU chain
-    using PC = wn::PCfg<F16, R, S, A>;     // multi-CU chain kept full (throughput)
     using elem = typename wn::Prec<F16>::elem;
 
     Implementation m_implementation;
     int m_numLayers, m_maxBatch, m_maxSamples, m_maxDilation, m_tiles, m_numCUs;
-    int m_org;           // resolved organisation: NVW_ORG_WG1 / WG2 / WG (by batch at run time) / STREAM / CHAIN / CHAIN1
-    bool m_streamMode;   // weights / conditioning packed for wn::wavenet_stream (else: per-wave streams of wavenet_wg / chain)
+    int m_org;           // resolved organisation: NVW_ORG_WG1 / WG2 / WG3 / WG (by batch at run time) / CHAIN / CHAIN1
     bool m_supported;    // false: this shape does not fit the CU (run() returns false, like the reference's unsupported variants)
-    int m_streamNS;      // LDS ring slots of the throughput kernel
     int m_chainLpc, m_chainStages;   // layers per chain stage, stages (layer stages + head)
-    int m_pipeChains, m_pipeGroups;  // wavenet_pipe: chains, groups of PC::G tiles per chain (0: not this organisation)
     bool m_tanhEmbed;
     int m_num_samples_per_chunk;
     int m_ringSlots;
@@ -98,16 +90,21 @@ protected:
     float* m_bias;      // fp32 biases
     elem* m_embedPrev;  // [A][R]
     elem* m_embedCur;
-    elem* m_cond;       // packed conditioning
+    elem* m_cond;       // packed conditioning (allocated by the first setInputs / setConditioning / packConditioning)
     int m_condRawSamples;
-    const float* m_condRaw;   // or: the caller's fp32 [N][L][maxBatch][2R] device tensor, consumed in place (setInputsDirect)
+    const void* m_condRaw;    // or: the caller's [N][L][maxBatch][2R] device tensor, consumed in place (setConditioningDirect)
+    int m_condRawKind;        // 1: fp32, 2: fp16 (T_data of the fp16 engine)
     float* m_outputSelectors;
     elem* m_ring;
     int *m_yInPrev, *m_yInCur, *m_yOut;
     float *m_XtOut, *m_skipOut, *m_Zs, *m_Za, *m_p;
     unsigned long long* m_mail;   // chain mailboxes
-    unsigned* m_chainStatus;      // [0] first time-out code of a chain launch (0 = fine)
+    unsigned* m_chainStatus;      // [0] time-out code of the chain launch in flight (0 = fine), [1] code of the latest launch that
+                                  // gave up, [2] launches that gave up and were re-run by wavenet_wg (wn::chain_settle_kernel)
     size_t m_mailBytes;
+    elem* m_ringShadow;           // the dilation rings as they were before the chain launch in flight ...
+    int* m_histShadow;            // ... and the sample history: what the fallback launch starts from
+    long long m_chainTimeoutTicks;
 
     float* m_stage;     // device staging for fp32 uploads from host pointers
     size_t m_stageElems;
@@ -118,6 +115,7 @@ protected:
     short* m_pcm;       // [maxBatch][maxSamples] int16, allocated on first setAudioOut
     short* m_mulaw;     // [A] PCM value of every sample index
     short* m_pcmUser;   // caller's buffer (host or device), filled wherever yOut is
+    size_t m_pcmUserElems;   // its size in int16 values when the caller said so (0: unknown)
 
     static bool isDevicePtr(const void* ptr) {
         hipPointerAttribute_t attr;
@@ -162,13 +160,6 @@ protected:
                            C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS, gateRT);
         gpuErrChk(hipGetLastError());
     }
-    // same for the shared stream of the throughput kernel (fragment offset inside the one stream)
-    void packWeightStream(size_t fragOff, const float* src, int M, int K, int rowperm, int gate = 0) {
-        const float* d = onDevice(src, (size_t)M * K);
-        hipLaunchKernelGGL((wn::pack_weight_stream_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0,
-                           m_wblob + fragOff * SC::FRAG_ELEMS, d, M, K, rowperm, gate);
-        gpuErrChk(hipGetLastError());
-    }
     void convertTo(elem* dst, const float* src, size_t n) {
         const float* d = onDevice(src, n);
         hipLaunchKernelGGL((wn::convert_kernel<F16>), dim3(gridFor(n)), dim3(256), 0, 0, dst, d, n);
@@ -183,7 +174,7 @@ protected:
     }
     // DUMP = false (no activation dump code at all) exists for the fp16 engine, the production path;
     // the fp32 engine is the parity mode and always carries the dump
-    template <int BT, bool EMB, bool DUMP, bool RAW> bool launchK(wn::Params& p, int tiles, int nEmb, hipStream_t stream) {
+    template <int BT, bool EMB, bool DUMP, int RAW> bool launchK(wn::Params& p, int tiles, int nEmb, hipStream_t stream) {
         using CB = wn::Cfg<F16, R, S, A, BT>;
         const int grid = (tiles + BT - 1) / BT;
         p.embLds = nEmb;
@@ -191,34 +182,41 @@ protected:
                            ldsNeed<BT>(m_numLayers, nEmb), stream, p);
         return hipGetLastError() == hipSuccess;
     }
-    template <int BT, bool DUMP, bool RAW> bool launchE(wn::Params& p, int tiles, hipStream_t stream) {
+    template <int BT, bool DUMP, int RAW> bool launchE(wn::Params& p, int tiles, hipStream_t stream) {
         const int nEmb = embTables<BT>();
         return nEmb ? launchK<BT, true, DUMP, RAW>(p, tiles, nEmb, stream) : launchK<BT, false, DUMP, RAW>(p, tiles, 0, stream);
     }
-    template <int BT> bool launch(wn::Params& p, int tiles, hipStream_t stream) {
-        const bool raw = p.condRaw != NULL;
+    template <int BT, bool DUMP> bool launchD(wn::Params& p, int tiles, hipStream_t stream) {
         if constexpr (F16) {
-            if (!p.dump) return raw ? launchE<BT, false, true>(p, tiles, stream) : launchE<BT, false, false>(p, tiles, stream);
+            if (p.condRawKind == 2) return launchE<BT, DUMP, 2>(p, tiles, stream);
         }
-        return raw ? launchE<BT, true, true>(p, tiles, stream) : launchE<BT, true, false>(p, tiles, stream);
+        return p.condRawKind == 1 ? launchE<BT, DUMP, 1>(p, tiles, stream) : launchE<BT, DUMP, 0>(p, tiles, stream);
     }
-    template <int BT, bool EMB, bool DUMP, bool RAW> void allowLdsK() {
+    template <int BT> bool launch(wn::Params& p, int tiles, hipStream_t stream) {
+        if constexpr (F16) {
+            if (!p.dump) return launchD<BT, false>(p, tiles, stream);
+        }
+        return launchD<BT, true>(p, tiles, stream);
+    }
+    template <int BT, bool EMB, bool DUMP, int RAW> void allowLdsK() {
         const size_t need = ldsNeed<BT>(m_numLayers, EMB ? embTables<BT>() : 0);
         if (need <= kLdsMax)
             gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
-    template <int BT> void allowLds() {
-        allowLdsK<BT, false, true, false>();
-        allowLdsK<BT, true, true, false>();
-        allowLdsK<BT, false, true, true>();
-        allowLdsK<BT, true, true, true>();
+    template <int BT, bool DUMP> void allowLdsD() {
+        allowLdsK<BT, false, DUMP, 0>();
+        allowLdsK<BT, true, DUMP, 0>();
+        allowLdsK<BT, false, DUMP, 1>();
+        allowLdsK<BT, true, DUMP, 1>();
         if constexpr (F16) {
-            allowLdsK<BT, false, false, false>();
-            allowLdsK<BT, true, false, false>();
-            allowLdsK<BT, false, false, true>();
-            allowLdsK<BT, true, false, true>();
+            allowLdsK<BT, false, DUMP, 2>();
+            allowLdsK<BT, true, DUMP, 2>();
         }
+    }
+    template <int BT> void allowLds() {
+        allowLdsD<BT, true>();
+        if constexpr (F16) allowLdsD<BT, false>();
     }
     float* headBias() { return m_bias + (size_t)m_numLayers * C::BIAS_L; }
 
@@ -231,14 +229,9 @@ protected:
         return (L + ns - 1) / ns;
     }
     bool chainFits(int lpc, int tiles) const { return lpc > 0 && chainStagesFor(m_numLayers, lpc) * tiles <= m_numCUs; }
-    bool streamFits() const { return m_streamNS >= SC::MIN_NS; }
-    // The single-workgroup organisations by batch size: up to three tiles per CU run in the latency kernel
-    // (one, two or -- fp16, R <= 64 -- three tiles split over the 4 SIMDs of a CU); beyond that every SIMD gets
-    // its own tile and the weights are streamed once per CU through an LDS ring.
-    int singleOrg(int tiles) const {
-        if (tiles > 2 * m_numCUs && tiles <= 3 * m_numCUs && wg3Fits()) return NVW_ORG_WG3;
-        return (tiles > 2 * m_numCUs && streamFits()) ? NVW_ORG_STREAM : NVW_ORG_WG;
-    }
+    // The single-workgroup organisation: one, two or -- fp16, R <= 64 -- three tiles per workgroup (split over the 4 SIMDs
+    // of a CU) by batch size, see wgTiles(); beyond three tiles per CU the launch simply has more workgroups than CUs.
+    int singleOrg(int) const { return NVW_ORG_WG; }
     // Per-sample time models (microseconds) of the organisations that can run `tiles` tiles, from the
     // shape: weight bytes per sample W, layers L, CUs.  Constants measured on MI355X:
     // a CU streams 58 B/clk of weights at ~2.1 GHz beside ~0.45 us of dependent chain per layer; a chain
@@ -267,40 +260,13 @@ protected:
                 default: org = pickOrganisation(tiles); break;
             }
         }
-        if (org == NVW_ORG_STREAM && !streamFits()) org = NVW_ORG_WG;
         if (org == NVW_ORG_CHAIN && !chainFits(chainLpcMax(m_numLayers), tiles)) org = singleOrg(tiles);
         if (org == NVW_ORG_CHAIN1 && !(CC::SUPPORTED && chainFits(1, tiles))) org = singleOrg(tiles);
-        m_pipeChains = m_pipeGroups = 0;
-        if (org == NVW_ORG_PIPE) {
-            if (!pipeGeometry(tiles, m_pipeChains, m_pipeGroups)) {
-                m_pipeChains = m_pipeGroups = 0;
-                org = singleOrg(tiles);
-            }
-        }
         m_org = org;
-        m_streamMode = org == NVW_ORG_STREAM;
-        m_chainLpc = org == NVW_ORG_CHAIN ? chainLpcMax(m_numLayers) : org == NVW_ORG_CHAIN1 ? 1 : org == NVW_ORG_PIPE ? pipeLpc(m_numLayers) : 0;
+        m_chainLpc = org == NVW_ORG_CHAIN ? chainLpcMax(m_numLayers) : org == NVW_ORG_CHAIN1 ? 1 : 0;
         m_chainStages = m_chainLpc ? chainStagesFor(m_numLayers, m_chainLpc) : 0;
     }
-    bool isChain() const { return m_chainLpc > 0 && m_pipeGroups == 0; }
-    bool isPipe() const { return m_pipeGroups > 0; }
-    // wavenet_pipe geometry for `tiles` tiles: as many chains as the GPU holds, groups of PC::G tiles per chain
-    static int pipeLpc(int L) {
-        if (!PC::SUPPORTED) return 0;
-        const int ns = (L + PC::LPC - 1) / PC::LPC;
-        return (L + ns - 1) / ns;
-    }
-    bool pipeGeometry(int tiles, int& chains, int& groups) const {
-        const int lpc = pipeLpc(m_numLayers);
-        if (lpc == 0) return false;
-        const int maxChains = m_numCUs / chainStagesFor(m_numLayers, lpc);
-        if (maxChains < 1) return false;
-        const int perChain = (tiles + maxChains - 1) / maxChains;
-        groups = (perChain + PC::G - 1) / PC::G;
-        if (groups > PC::MAX_GROUPS) return false;
-        chains = (tiles + groups * PC::G - 1) / (groups * PC::G);
-        return true;
-    }
+    bool isChain() const { return m_chainLpc > 0; }
     // tiles per workgroup of wn::wavenet_wg for a batch of `tiles` tiles
     static constexpr bool WG3 = F16 && R <= 64;   // shapes with a three-tile instantiation
     bool wg3Fits() const {
@@ -308,8 +274,9 @@ protected:
         return false;
     }
     int wgTiles(int tiles) const {
-        if (m_org == NVW_ORG_WG3 && wg3Fits()) return 3;
-        const bool two = m_org == NVW_ORG_WG2 || m_org == NVW_ORG_WG3 || (m_org == NVW_ORG_WG && tiles > m_numCUs);
+        const bool three = m_org == NVW_ORG_WG3 || (m_org == NVW_ORG_WG && tiles > 2 * m_numCUs);
+        if (three && wg3Fits()) return 3;
+        const bool two = three || m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs);
         return (two && ldsFits<2>()) ? 2 : 1;
     }
 
@@ -318,9 +285,10 @@ public:
                    bool tanhEmbed = true, int organisation = NVW_ORG_AUTO)
         : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
-          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_condRaw(NULL), m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0),
-          m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL), m_mulaw(NULL), m_pcmUser(NULL),
-          m_stageUsed(0) {
+          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0),
+          m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0), m_ringShadow(NULL), m_histShadow(NULL),
+          m_chainTimeoutTicks(wn::kChainTimeoutTicks), m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL),
+          m_mulaw(NULL), m_pcmUser(NULL), m_pcmUserElems(0), m_stageUsed(0) {
         assert(numLayers >= 2 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
         assert(numLayers <= wn::kMaxLayers);
         {
@@ -330,27 +298,21 @@ public:
             gpuErrChk(hipGetDeviceProperties(&prop, dev));
             m_numCUs = prop.multiProcessorCount;
         }
-        {
-            const size_t biasBytes = ((size_t)numLayers * SC::BIAS_L + 2 * A) * sizeof(float);
-            long ns = ((long)kLdsMax - (long)biasBytes) / ((long)SC::CH * 1024);
-            m_streamNS = (int)(ns > 6 ? 6 : ns);
-        }
         resolveOrganisation(organisation);
         // The bias table of the whole model lives in the LDS of a wavenet_wg workgroup: a model whose
         // table does not fit cannot run there (the reference prints and returns false for shapes a
         // variant does not support, nv_wavenet_singleblock.cuh:273-286)
-        m_supported = isChain() || isPipe() || m_streamMode || ldsFits<1>();
+        m_supported = isChain() || ldsFits<1>();
         if (!m_supported)
             fprintf(stderr, "nvWavenetInfer: R=%d S=%d A=%d with %d layers needs %zu bytes of LDS (> 160 KiB): unsupported\n", R,
                     S, A, numLayers, ldsNeed<1>(numLayers, 0));
 
-        // conditioning / ring are allocated for whole workgroups: 4 tiles (throughput kernel), 2 (two tiles
-        // per workgroup may be chosen), else exactly the tiles of the batch
+        // conditioning / ring are allocated for whole workgroups (two or three tiles per workgroup may be chosen), else
+        // exactly the tiles of the batch
         {
             const int tiles = (batchSize + 15) / 16;
-            const int group = m_streamMode ? 4 : (isChain() || isPipe()) ? 1 : wgTiles(tiles);
+            const int group = isChain() ? 1 : wgTiles(tiles);
             m_tiles = (tiles + group - 1) / group * group;
-            if (isPipe()) m_tiles = m_pipeChains * m_pipeGroups * PC::G;
         }
 
         // dilation schedule (nv_wavenet.cuh:99,110-111): d doubles per layer, back to 1 past maxDilation
@@ -364,8 +326,7 @@ public:
             m_ringSlots = slots;
         }
 
-        const size_t wElems = m_streamMode ? SC::streamFrags(numLayers) * SC::FRAG_ELEMS
-                                           : (size_t)C::NW * C::waveStreamFrags(numLayers) * C::FRAG_ELEMS;
+        const size_t wElems = (size_t)C::NW * C::waveStreamFrags(numLayers) * C::FRAG_ELEMS;
         gpuErrChk(hipMalloc(&m_wblob, wElems * sizeof(elem)));
         gpuErrChk(hipMemset(m_wblob, 0, wElems * sizeof(elem)));
         const size_t bElems = (size_t)numLayers * C::BIAS_L + 2 * A;
@@ -376,15 +337,14 @@ public:
         gpuErrChk(hipMemset(m_embedPrev, 0, (size_t)A * R * sizeof(elem)));
         gpuErrChk(hipMemset(m_embedCur, 0, (size_t)A * R * sizeof(elem)));
 
-        const size_t condElems = (size_t)(numSamples + 1) * numLayers * m_tiles * 16 * 2 * R;   // + one padding sample
-        gpuErrChk(hipMalloc(&m_cond, condElems * sizeof(elem)));
-        gpuErrChk(hipMemset(m_cond, 0, condElems * sizeof(elem)));
+        // (the packed conditioning -- the largest buffer by far -- is allocated when a caller first packs some: engines
+        //  that only ever read the conditioning in place never pay for it)
         gpuErrChk(hipMalloc(&m_outputSelectors, (size_t)numSamples * batchSize * sizeof(float)));
         gpuErrChk(hipMemset(m_outputSelectors, 0, (size_t)numSamples * batchSize * sizeof(float)));
 
-        const size_t ringElems = (size_t)m_tiles * m_ringSlots * R * 16;
-        gpuErrChk(hipMalloc(&m_ring, ringElems * sizeof(elem)));
-        gpuErrChk(hipMemset(m_ring, 0, ringElems * sizeof(elem)));
+        const size_t ringBytes = ringElems() * sizeof(elem);
+        gpuErrChk(hipMalloc(&m_ring, ringBytes));
+        gpuErrChk(hipMemset(m_ring, 0, ringBytes));
 
         gpuErrChk(hipMalloc(&m_yInPrev, batchSize * sizeof(int)));
         gpuErrChk(hipMalloc(&m_yInCur, batchSize * sizeof(int)));
@@ -404,16 +364,6 @@ public:
 
         gpuErrChk(hipMalloc(&m_chainStatus, 4 * sizeof(unsigned)));
         gpuErrChk(hipMemset(m_chainStatus, 0, 4 * sizeof(unsigned)));
-        if (isPipe()) {
-            m_mailBytes = PC::mailGranules(m_pipeChains, m_chainStages, m_pipeGroups) * sizeof(unsigned long long);
-            gpuErrChk(hipMalloc(&m_mail, m_mailBytes));
-            gpuErrChk(hipMemset(m_mail, 0, m_mailBytes));
-            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_pipe<F16, R, S, A, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)PC::ldsBytes()));
-            if constexpr (F16)
-                gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_pipe<F16, R, S, A, false>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)PC::ldsBytes()));
-        }
         if (isChain()) {
             m_mailBytes = CC::mailGranules((batchSize + 15) / 16, m_chainStages) * sizeof(unsigned long long);
             gpuErrChk(hipMalloc(&m_mail, m_mailBytes));
@@ -423,24 +373,21 @@ public:
             if constexpr (F16)
                 gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_chain<F16, R, S, A, false>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::ldsBytes()));
+            if (chainHasFallback()) {
+                gpuErrChk(hipMalloc(&m_ringShadow, ringBytes));
+                gpuErrChk(hipMalloc(&m_histShadow, 2 * (size_t)batchSize * sizeof(int)));
+            }
         }
 
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
 
-        if (m_supported && !isChain() && !isPipe() && !m_streamMode) {
+        if (ldsFits<1>()) {            // (a chain engine launches wavenet_wg as its fallback)
             allowLds<1>();
-            allowLds<2>();
-            if constexpr (WG3) allowLds<3>();
-        }
-        if (m_streamMode) {
-            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_stream<F16, R, S, A, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)SC::ldsBytes(numLayers, m_streamNS)));
-            if constexpr (F16)
-                gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_stream<F16, R, S, A, false>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)SC::ldsBytes(numLayers, m_streamNS)));
+            if (!isChain()) {
+                allowLds<2>();
+                if constexpr (WG3) allowLds<3>();
+            }
         }
         gpuErrChk(hipDeviceSynchronize());
     }
@@ -451,7 +398,7 @@ public:
         gpuErrChk(hipFree(m_bias));
         gpuErrChk(hipFree(m_embedPrev));
         gpuErrChk(hipFree(m_embedCur));
-        gpuErrChk(hipFree(m_cond));
+        if (m_cond) gpuErrChk(hipFree(m_cond));
         gpuErrChk(hipFree(m_outputSelectors));
         gpuErrChk(hipFree(m_ring));
         gpuErrChk(hipFree(m_yInPrev));
@@ -464,6 +411,8 @@ public:
         gpuErrChk(hipFree(m_p));
         gpuErrChk(hipFree(m_chainStatus));
         if (m_mail) gpuErrChk(hipFree(m_mail));
+        if (m_ringShadow) gpuErrChk(hipFree(m_ringShadow));
+        if (m_histShadow) gpuErrChk(hipFree(m_histShadow));
         if (m_stage) gpuErrChk(hipFree(m_stage));
         if (m_pcm) gpuErrChk(hipFree(m_pcm));
         if (m_mulaw) gpuErrChk(hipFree(m_mulaw));
@@ -471,14 +420,17 @@ public:
 
     // false: the shape does not fit this GPU's CUs in the chosen organisation; run() returns false
     bool supported() const { return m_supported; }
-    // 0 when every multi-CU launch so far ran to completion; else the code of the first hand-off that
-    // timed out (0x100+stage: x, 0x200+stage: skip sums, 0x300: head).  Synchronises the device.
-    unsigned chainStatus() {
-        unsigned s = 0;
-        gpuErrChk(hipDeviceSynchronize());
-        gpuErrChk(hipMemcpy(&s, m_chainStatus, sizeof(unsigned), hipMemcpyDeviceToHost));
-        return s;
-    }
+    // Multi-CU launches.  A wavenet_chain launch whose workgroups are not all resident in time (other work holds CUs:
+    // another stream, engine or process) gives up -- every spin is bounded -- and the SAME stream then re-runs the
+    // launch's samples on wavenet_wg from the state the launch started with (launchChain), so the samples delivered are
+    // the right ones either way.  chainStatus(): 0, or the code of a give-up that could NOT be repaired (0x100+stage: x,
+    // 0x200+stage: skip sums, 0x300: head, 0x400+: placement exchange); chainFallbacks(): launches that were re-run;
+    // chainLastTimeout(): the code of the latest of them.  All three synchronise the device.
+    unsigned chainStatus() { return statusWord(0); }
+    unsigned chainFallbacks() { return statusWord(2); }
+    unsigned chainLastTimeout() { return statusWord(1); }
+    // bound of every hand-off spin of the chain (default 1.5 s)
+    void setChainTimeoutMs(double ms) { m_chainTimeoutTicks = (long long)(ms * 1e5); }
 
     // ---- model upload: fp32 in, host or device pointers, data is copied ---------------------
     // embedPrev / embedCur: [A][R]   (nv_wavenet.cuh:396-399)
@@ -494,52 +446,28 @@ public:
         assert(layer >= 0 && layer < m_numLayers);
         stageBegin((size_t)5 * R * R + (size_t)S * R + 3 * R + S + 32);
         float* b = m_bias + (size_t)layer * C::BIAS_L;
-        if (m_streamMode) {
-            const size_t sf = (size_t)layer * SC::FLP;
-            packWeightStream(sf + SC::O_PREV, Wprev, 2 * R, R, 0, 1);
-            packWeightStream(sf + SC::O_CUR, Wcur, 2 * R, R, 0, 1);
-            packWeightStream(sf + SC::O_RES, Wres, R, R, 0);
-            // the skip GEMM of layer l is consumed one body later (the head body after the last layer)
-            const size_t skipAt = (layer + 1 < m_numLayers) ? sf + SC::FLP + SC::O_SKIP
-                                                            : (size_t)m_numLayers * SC::FLP + SC::H_SKIP;
-            packWeightStream(skipAt, Wskip, S, R, 0);
-            gpuErrChk(hipMemcpyAsync(b, Bh, 2 * R * sizeof(float), hipMemcpyDefault, 0));
-            if constexpr (F16) {   // the fp16 gate works on pre-scaled pre-activations (wn::gate1)
-                hipLaunchKernelGGL((wn::scale_gate_bias_kernel<F16>), dim3(1), dim3(256), 0, 0, b, R);
-                gpuErrChk(hipGetLastError());
-            }
-            gpuErrChk(hipMemcpyAsync(b + 2 * R, Bres, R * sizeof(float), hipMemcpyDefault, 0));
-            gpuErrChk(hipMemcpyAsync(b + 3 * R, Bskip, S * sizeof(float), hipMemcpyDefault, 0));
-        } else {
-            // one launch packs the four matrices and the three bias vectors of the layer
-            wn::LayerSrc src;
-            src.Wprev = onDevice(Wprev, (size_t)2 * R * R);
-            src.Wcur = onDevice(Wcur, (size_t)2 * R * R);
-            src.Bh = onDevice(Bh, 2 * R);
-            src.Wres = onDevice(Wres, (size_t)R * R);
-            src.Bres = onDevice(Bres, R);
-            src.Wskip = onDevice(Wskip, (size_t)S * R);
-            src.Bskip = onDevice(Bskip, S);
-            hipLaunchKernelGGL((wn::pack_layer_kernel<F16>), dim3(gridFor((size_t)5 * R * R + (size_t)S * R)), dim3(256), 0, 0,
-                               m_wblob, b, src, R, S, C::NW, C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS,
-                               (int)C::streamPos(layer, C::O_PREV, m_numLayers), (int)C::streamPos(layer, C::O_CUR, m_numLayers),
-                               (int)C::streamPos(layer, C::O_RES, m_numLayers), (int)C::streamPos(layer, C::O_SKIP, m_numLayers));
-            gpuErrChk(hipGetLastError());
-        }
+        // one launch packs the four matrices and the three bias vectors of the layer
+        wn::LayerSrc src;
+        src.Wprev = onDevice(Wprev, (size_t)2 * R * R);
+        src.Wcur = onDevice(Wcur, (size_t)2 * R * R);
+        src.Bh = onDevice(Bh, 2 * R);
+        src.Wres = onDevice(Wres, (size_t)R * R);
+        src.Bres = onDevice(Bres, R);
+        src.Wskip = onDevice(Wskip, (size_t)S * R);
+        src.Bskip = onDevice(Bskip, S);
+        hipLaunchKernelGGL((wn::pack_layer_kernel<F16>), dim3(gridFor((size_t)5 * R * R + (size_t)S * R)), dim3(256), 0, 0,
+                           m_wblob, b, src, R, S, C::NW, C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS,
+                           (int)C::streamPos(layer, C::O_PREV, m_numLayers), (int)C::streamPos(layer, C::O_CUR, m_numLayers),
+                           (int)C::streamPos(layer, C::O_RES, m_numLayers), (int)C::streamPos(layer, C::O_SKIP, m_numLayers));
+        gpuErrChk(hipGetLastError());
         gpuErrChk(hipStreamSynchronize(0));
     }
     // col-major Wzs AxS, Bzs A, Wza AxA, Bza A (nv_wavenet.cuh:410-415)
     virtual void setOutWeights(float* Wzs, float* Bzs, float* Wza, float* Bza) {
         stageBegin((size_t)A * S + (size_t)A * A + 16);
         const size_t hf = C::headOffsetFrags(m_numLayers);
-        if (m_streamMode) {
-            const size_t sh = (size_t)m_numLayers * SC::FLP;
-            packWeightStream(sh + SC::H_ZS, Wzs, A, S, 0);
-            packWeightStream(sh + SC::H_ZA, Wza, A, A, 1);   // lane-contiguous logit rows
-        } else {
-            packWeight(hf + C::O_ZS, Wzs, A, S, 0);
-            packWeight(hf + C::O_ZA, Wza, A, A, 0);
-        }
+        packWeight(hf + C::O_ZS, Wzs, A, S, 0);
+        packWeight(hf + C::O_ZA, Wza, A, A, 0);
         gpuErrChk(hipMemcpyAsync(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault, 0));
         gpuErrChk(hipMemcpyAsync(headBias() + A, Bza, A * sizeof(float), hipMemcpyDefault, 0));
         gpuErrChk(hipStreamSynchronize(0));
@@ -563,21 +491,26 @@ public:
     void setConditioning(float* Lh) { setConditioning(Lh, m_maxSamples); }
     void setConditioning(float* Lh, int numSamples, hipStream_t stream = 0) {
         assert(numSamples > 0 && numSamples <= m_maxSamples);
-        m_condRaw = NULL;
-        gpuErrChk(hipMemsetAsync(m_chainStatus, 0, sizeof(unsigned), stream));   // a new utterance starts from a clean state
-        hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, stream, m_yInPrev, m_yInCur, m_maxBatch);
-        gpuErrChk(hipGetLastError());
+        resetHistory(stream);
         packConditioning(Lh, 0, numSamples, stream);
         gpuErrChk(hipStreamSynchronize(stream));
     }
     // Packs samples [firstSample, firstSample + count) of the conditioning (Lh points at sample firstSample)
     // into the engine's fragment order, asynchronously on `stream` when Lh is device memory: lets a caller
-    // stream the conditioning chunk by chunk behind run_partial() of the previous chunk.
+    // stream the conditioning chunk by chunk behind run_partial() of the previous chunk.  From here on the engine
+    // reads the packed copy (a tensor handed over with setConditioningDirect is let go).
     void packConditioning(float* Lh, int firstSample, int count, hipStream_t stream = 0) {
         assert(firstSample >= 0 && count > 0 && firstSample + count <= m_maxSamples);
+        m_condRaw = NULL;
+        m_condRawKind = 0;
         const size_t rows = (size_t)count * m_numLayers;
         const size_t srcPerRow = (size_t)m_maxBatch * 2 * R;
         const size_t dstPerRow = (size_t)m_tiles * 16 * 2 * R;
+        if (!m_cond) {
+            const size_t condElems = (size_t)(m_maxSamples + 1) * m_numLayers * dstPerRow;   // + one padding sample
+            gpuErrChk(hipMalloc(&m_cond, condElems * sizeof(elem)));
+            gpuErrChk(hipMemsetAsync(m_cond, 0, condElems * sizeof(elem), stream));
+        }
         elem* const dst0 = m_cond + (size_t)firstSample * m_numLayers * dstPerRow;
         const bool dev = isDevicePtr(Lh);
         // host sources go through the staging buffer in chunks of <= 64 Mi floats
@@ -595,31 +528,29 @@ public:
             // one workgroup per (row, tile): 16 utterances x 2R channels, read and written coalesced
             const size_t nblk = nr * (size_t)m_tiles;
             const int grid = (int)(nblk > 65536 ? 65536 : nblk);
-            if (m_streamMode)
-                hipLaunchKernelGGL((wn::pack_cond_tiled_kernel<F16, R, true>), dim3(grid), dim3(256), 0, stream,
-                                   m_cond + ((size_t)firstSample * m_numLayers + r0) * dstPerRow, src, nr, m_maxBatch, m_tiles);
-            else
-                hipLaunchKernelGGL((wn::pack_cond_tiled_kernel<F16, R, false>), dim3(grid), dim3(256), 0, stream,
-                                   dst0 + r0 * dstPerRow, src, nr, m_maxBatch, m_tiles);
+            hipLaunchKernelGGL((wn::pack_cond_tiled_kernel<F16, R>), dim3(grid), dim3(256), 0, stream, dst0 + r0 * dstPerRow, src, nr,
+                               m_maxBatch, m_tiles);
             gpuErrChk(hipGetLastError());
         }
     }
     // Device-resident conditioning WITHOUT the copy (the reference's own recommendation, README.md:44; SURVEY.md 8f
-    // rank 1): Lh is the caller's fp32 [numSamples][L][maxBatch][2R] tensor in device memory; the kernels read it in
-    // place (16 bytes per lane and gate tile) and nothing is packed.  The caller keeps it alive and unchanged until
-    // the run calls that follow have completed.  Resets the sample history like setInputs.  The loader / consumer
-    // kernel and wavenet_pipe have no in-place path: there (and for host pointers) this is setConditioning.
-    void setConditioningDirect(float* Lh, int numSamples) {
+    // rank 1): Lh is the caller's [numSamples][L][maxBatch][2R] tensor in device memory, fp32 (precision = 32) or -- fp16
+    // engine -- T_data = fp16 (precision = 16: half the bytes; the reference keeps m_Lh in T_data, nv_wavenet.cuh:326); the
+    // kernels read it in place (16 / 8 bytes per lane and gate tile) and nothing is packed.  The caller keeps it alive and
+    // unchanged until the run calls that follow have completed.  Resets the sample history like setInputs.  Host pointers
+    // (fp32 only) fall back to setConditioning.
+    void setConditioningDirect(const void* Lh, int numSamples, int precision = 32) {
         assert(numSamples > 0 && numSamples <= m_maxSamples);
-        if (m_streamMode || isPipe() || !isDevicePtr(Lh)) {
-            setConditioning(Lh, numSamples);
+        assert(precision == 32 || (precision == 16 && F16));
+        if (!isDevicePtr(Lh)) {
+            assert(precision == 32);
+            setConditioning((float*)Lh, numSamples);
             return;
         }
-        hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
-        gpuErrChk(hipGetLastError());
-        gpuErrChk(hipMemsetAsync(m_chainStatus, 0, sizeof(unsigned), 0));
+        resetHistory(0);
         gpuErrChk(hipStreamSynchronize(0));
         m_condRaw = Lh;
+        m_condRawKind = precision == 16 ? 2 : 1;
         m_condRawSamples = numSamples;
     }
     bool conditioningInPlace() const { return m_condRaw != NULL; }
@@ -637,10 +568,12 @@ public:
         m_rngSeed = seed;
     }
     // int16 PCM beside the indices: pcm[b][t] = int16(32768 * mu_law_decode(y[b][t], A))
-    // (pytorch/utils.py:62-70, inference.py:58-60).  pcmOut: caller-owned [maxBatch][maxSamples]
-    // int16, host or device; filled by run / run_partial / run_chunks wherever yOut is; NULL disables.
-    void setAudioOut(short* pcmOut) {
+    // (pytorch/utils.py:62-70, inference.py:58-60).  pcmOut: caller-owned [batch][num_samples] int16 of the run calls
+    // that follow, host or device; filled by run / run_partial / run_chunks wherever yOut is; NULL disables.
+    // pcmElems: the buffer's size in int16 values (0 = not stated); a stated size is checked by every run call.
+    void setAudioOut(short* pcmOut, size_t pcmElems = 0) {
         m_pcmUser = pcmOut;
+        m_pcmUserElems = pcmOut ? pcmElems : 0;
         if (pcmOut && !m_pcm) {
             gpuErrChk(hipMalloc(&m_pcm, (size_t)m_maxSamples * m_maxBatch * sizeof(short)));
             gpuErrChk(hipMemset(m_pcm, 0, (size_t)m_maxSamples * m_maxBatch * sizeof(short)));
@@ -670,21 +603,10 @@ public:
     void kernelInfo(int batch_size, bool dumpActivations, char* buf, int n) const {
         const int tiles = (batch_size + 15) / 16;
         const bool dump = F16 ? dumpActivations : true;
-        if (isPipe()) {
-            snprintf(buf, n, "wn::wavenet_pipe<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d groups=%d tiles/group=%d wgs=%d lds=%zu",
-                     F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, m_pipeChains, m_pipeGroups, PC::G,
-                     m_chainStages * m_pipeChains, PC::ldsBytes());
-            return;
-        }
         if (isChain()) {
             snprintf(buf, n, "wn::wavenet_chain<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d wgs=%d lds=%zu",
                      F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, tiles, m_chainStages * tiles,
                      CC::ldsBytes());
-            return;
-        }
-        if (m_streamMode) {
-            snprintf(buf, n, "wn::wavenet_stream<%s,%d,%d,%d,DUMP=%d> tiles/wg=4 wgs=%d lds=%zu", F16 ? "fp16" : "fp32", R,
-                     S, A, dump ? 1 : 0, (tiles + 3) / 4, SC::ldsBytes(m_numLayers, m_streamNS));
             return;
         }
         const int bt = wgTiles(tiles);
@@ -696,8 +618,8 @@ public:
                 lds = ldsNeed<3>(m_numLayers, nEmb);
             }
         }
-        snprintf(buf, n, "wn::wavenet_wg<%s,%d,%d,%d,BT=%d,EMBLDS=%d,DUMP=%d> tiles/wg=%d wgs=%d lds=%zu",
-                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, bt, (tiles + bt - 1) / bt, lds);
+        snprintf(buf, n, "wn::wavenet_wg<%s,%d,%d,%d,BT=%d,EMBLDS=%d,DUMP=%d,RAW=%d> tiles/wg=%d wgs=%d lds=%zu",
+                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, m_condRaw ? m_condRawKind : 0, bt, (tiles + bt - 1) / bt, lds);
     }
 
     // ---- debug getters: last generated sample's activations, reference layouts --------------
@@ -775,7 +697,7 @@ public:
         }
         if (!stream) gpuErrChk(hipStreamDestroy(genStream));
         gpuErrChk(hipStreamDestroy(outStream));
-        if ((isChain() || isPipe()) && chainStatus() != 0) ok = false;   // (everything has completed: the check costs nothing)
+        if (isChain() && chainStatus() != 0) ok = false;   // (everything has completed: the check costs nothing)
         return ok;
     }
 
@@ -789,6 +711,9 @@ public:
         assert(batch_size % batch_size_per_block == 0);
         assert(batch_size > 0 && batch_size <= m_maxBatch);
         assert(num_samples <= m_maxSamples);
+        assert(m_condRaw != NULL || m_cond != NULL);                       // some conditioning has been handed over
+        assert(m_condRaw == NULL || num_samples <= m_condRawSamples);      // ... and the in-place tensor covers the run
+        assert(m_pcmUser == NULL || m_pcmUserElems == 0 || m_pcmUserElems >= (size_t)batch_size * num_samples);
         if (m_implementation == SINGLE_BLOCK) assert(S <= 4 * R);
         if (!m_supported) return false;
 
@@ -799,6 +724,8 @@ public:
         p.embCur = m_embedCur;
         p.cond = m_cond;
         p.condRaw = m_condRaw;
+        p.condRawKind = m_condRaw ? m_condRawKind : 0;
+        p.gate = NULL;
         p.sel = m_outputSelectors;
         p.ring = m_ring;
         p.maxDilation = m_maxDilation;
@@ -820,40 +747,18 @@ public:
         if (p.initSample + p.count > num_samples) p.count = num_samples - p.initSample;
         p.ringSlots = m_ringSlots;
         p.tiles = m_tiles;
+        p.tileBase = 0;
         p.tanhEmbed = m_tanhEmbed ? 1 : 0;
         p.dump = dumpActivations ? 1 : 0;
         p.embLds = 0;
         p.useRng = m_useRng ? 1 : 0;
         p.rngKey0 = (unsigned)m_rngSeed;
         p.rngKey1 = (unsigned)(m_rngSeed >> 32);
-        // rings + conditioning of many tiles stream through HBM: keep them from evicting the weights
-        p.ntStream = ((size_t)((batch_size + 15) / 16) * m_ringSlots * R * 16 * sizeof(elem) > ((size_t)16 << 20)) ? 1 : 0;
         m_lastStride = num_samples;
         if (p.count <= 0) return true;
 
         const int tiles = (batch_size + 15) / 16;
-        bool result;
-        if (isPipe()) {
-            result = launchPipe(p, tiles, stream);
-        } else if (isChain()) {
-            result = launchChain(p, tiles, stream);
-        } else if (m_streamMode) {
-            bool noDump = false;
-            if constexpr (F16) noDump = !p.dump;
-            if (noDump) {
-                if constexpr (F16)
-                    hipLaunchKernelGGL((wn::wavenet_stream<F16, R, S, A, false>), dim3((tiles + 3) / 4), dim3(512),
-                                       SC::ldsBytes(m_numLayers, m_streamNS), stream, p, m_streamNS);
-            } else {
-                hipLaunchKernelGGL((wn::wavenet_stream<F16, R, S, A, true>), dim3((tiles + 3) / 4), dim3(512),
-                                   SC::ldsBytes(m_numLayers, m_streamNS), stream, p, m_streamNS);
-            }
-            result = hipGetLastError() == hipSuccess;
-        } else if (wgTiles(tiles) == 3) {
-            result = false;
-            if constexpr (WG3) result = launch<3>(p, tiles, stream);
-        } else if (wgTiles(tiles) == 2) result = launch<2>(p, tiles, stream);
-        else result = launch<1>(p, tiles, stream);
+        bool result = isChain() ? launchChain(p, tiles, stream) : launchWg(p, tiles, stream);
         if (m_pcmUser != NULL) {
             // the indices of a finished sample are final: the expansion is a per-element map of yOut
             hipLaunchKernelGGL(wn::mulaw_pcm_kernel, dim3(gridFor((size_t)batch_size * p.count)), dim3(256), 0, stream,
@@ -877,10 +782,11 @@ public:
         m_num_samples_per_chunk = 0;
         return ok;
     }
-    // the sample history back to 128 (what setInputs does), asynchronously on `stream`
+    // the sample history back to 128 (what setInputs does) and a clean hand-off status, asynchronously on `stream`
     void resetHistory(hipStream_t stream = 0) {
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, stream, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
+        gpuErrChk(hipMemsetAsync(m_chainStatus, 0, sizeof(unsigned), stream));
     }
 
     bool run(int num_samples, int batch_size, int* yOut = NULL, int batch_size_per_block = 1,
@@ -890,48 +796,60 @@ public:
     }
 
 protected:
-    // the chain kept full: one launch, every (chain, stage) workgroup resident at the same time
-    bool launchPipe(wn::Params& p, int tiles, hipStream_t stream) {
-        wn::PipeParams pp;
-        pp.mail = m_mail;
-        pp.status = m_chainStatus;
-        pp.stages = m_chainStages;
-        pp.lpc = m_chainLpc;
-        pp.chains = m_pipeChains;
-        pp.groups = m_pipeGroups;
-        pp.tiles = tiles;
-        p.embLds = PC::embTables();
-        bool dump = true;
-        if constexpr (F16) dump = p.dump != 0;
-        gpuErrChk(hipMemsetAsync(m_mail, 0, m_mailBytes, stream));
-        const int grid = 8 * m_chainStages * ((m_pipeChains + 7) / 8);
-        if (dump) {
-            hipLaunchKernelGGL((wn::wavenet_pipe<F16, R, S, A, true>), dim3(grid), dim3(C::THREADS), PC::ldsBytes(), stream, p, pp);
-        } else {
-            if constexpr (F16)
-                hipLaunchKernelGGL((wn::wavenet_pipe<F16, R, S, A, false>), dim3(grid), dim3(C::THREADS), PC::ldsBytes(), stream, p, pp);
-        }
-        return hipGetLastError() == hipSuccess;
+    size_t ringElems() const { return (size_t)m_tiles * m_ringSlots * R * 16; }
+    unsigned statusWord(int i) {
+        unsigned s = 0;
+        gpuErrChk(hipDeviceSynchronize());
+        gpuErrChk(hipMemcpy(&s, m_chainStatus + i, sizeof(unsigned), hipMemcpyDeviceToHost));
+        return s;
     }
+    // wavenet_wg by batch size: one, two or three tiles per workgroup
+    bool launchWg(wn::Params& p, int tiles, hipStream_t stream) {
+        const int bt = wgTiles(tiles);
+        if (bt == 3) {
+            if constexpr (WG3) return launch<3>(p, tiles, stream);
+            return false;
+        }
+        return bt == 2 ? launch<2>(p, tiles, stream) : launch<1>(p, tiles, stream);
+    }
+    // a chain launch that gives up can be re-run by wavenet_wg when the model's bias table fits one workgroup's LDS
+    bool chainHasFallback() const { return ldsFits<1>(); }
 
-    // the multi-CU chain: every (tile, stage) workgroup must be resident at the same time, so tiles are
-    // launched in groups of at most CUs / stages chains; mailboxes are re-zeroed before every launch
+    // The multi-CU chain: every (tile, stage) workgroup must be resident at the same time, so tiles are launched in
+    // groups of at most CUs / stages chains; mailboxes are re-zeroed before every launch.  Residency cannot be
+    // guaranteed when other work shares the GPU, so every chain launch is bracketed, in stream order and without any
+    // host round trip: (1) rings and history of the launch's tiles are copied aside; (2) the chain runs; (3) if it
+    // gave up (status word set by the first spin that timed out), chain_restore_kernel puts rings and history back
+    // and a wavenet_wg launch gated on the status word generates the launch's samples instead (arithmetic and state
+    // layouts are the same in both organisations, bit for bit); (4) chain_settle_kernel counts the event and clears
+    // the word.  When the chain completes, (3) is two empty launches.
     bool launchChain(wn::Params& p, int tiles, hipStream_t stream) {
         wn::ChainParams cp;
         cp.mail = m_mail;
         cp.status = m_chainStatus;
         cp.stages = m_chainStages;
         cp.lpc = m_chainLpc;
-        p.embLds = CC::embTables();
+        cp.timeoutTicks = m_chainTimeoutTicks;
         const int perLaunch = m_numCUs / m_chainStages;
         if (perLaunch < 1) return false;
         bool dump = true;
         if constexpr (F16) dump = p.dump != 0;
+        const bool fallback = m_ringShadow != NULL;
+        const size_t ringTileElems = (size_t)m_ringSlots * R * 16;
         for (int t0 = 0; t0 < tiles; t0 += perLaunch) {
             cp.tile0 = t0;
             cp.chains = tiles - t0 < perLaunch ? tiles - t0 : perLaunch;
+            const int b0 = t0 * 16, nb = (p.batch - b0 < cp.chains * 16 ? p.batch - b0 : cp.chains * 16);
+            if (fallback) {
+                gpuErrChk(hipMemcpyAsync(m_ringShadow + t0 * ringTileElems, m_ring + t0 * ringTileElems,
+                                         cp.chains * ringTileElems * sizeof(elem), hipMemcpyDeviceToDevice, stream));
+                gpuErrChk(hipMemcpyAsync(m_histShadow + b0, m_yInPrev + b0, nb * sizeof(int), hipMemcpyDeviceToDevice, stream));
+                gpuErrChk(hipMemcpyAsync(m_histShadow + m_maxBatch + b0, m_yInCur + b0, nb * sizeof(int), hipMemcpyDeviceToDevice, stream));
+            }
             gpuErrChk(hipMemsetAsync(m_mail, 0, CC::mailGranules(cp.chains, m_chainStages) * sizeof(unsigned long long), stream));
             const int grid = 8 * m_chainStages * ((cp.chains + 7) / 8);
+            p.embLds = CC::embTables();
+            p.gate = NULL;
             if (dump) {
                 hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, true>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
             } else {
@@ -939,7 +857,48 @@ protected:
                     hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, false>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
             }
             if (hipGetLastError() != hipSuccess) return false;
+            if (fallback) {
+                const size_t n16 = cp.chains * ringTileElems * sizeof(elem) / 16;
+                hipLaunchKernelGGL(wn::chain_restore_kernel, dim3(gridFor(n16)), dim3(256), 0, stream, (const unsigned*)m_chainStatus,
+                                   (wn::uintx4*)(m_ring + t0 * ringTileElems), (const wn::uintx4*)(m_ringShadow + t0 * ringTileElems), n16,
+                                   m_yInPrev + b0, m_yInCur + b0, (const int*)(m_histShadow + b0), (const int*)(m_histShadow + m_maxBatch + b0), nb);
+                if (hipGetLastError() != hipSuccess) return false;
+                // the same samples for the same tiles on wavenet_wg, one tile per workgroup, only if the chain gave up
+                wn::Params q = p;
+                q.gate = m_chainStatus;
+                q.batch = b0 + nb;
+                const int nEmb = embTables<1>();
+                q.embLds = nEmb;
+                bool ok;
+                if (nEmb) ok = launchGated<true>(q, t0, cp.chains, nEmb, stream);
+                else ok = launchGated<false>(q, t0, cp.chains, 0, stream);
+                if (!ok) return false;
+                hipLaunchKernelGGL(wn::chain_settle_kernel, dim3(1), dim3(1), 0, stream, m_chainStatus);
+                if (hipGetLastError() != hipSuccess) return false;
+            }
         }
         return true;
+    }
+    // wavenet_wg<BT = 1> for tiles [tile0, tile0 + ntiles), gated on Params::gate
+    template <bool EMB> bool launchGated(wn::Params& q, int tile0, int ntiles, int nEmb, hipStream_t stream) {
+        q.tileBase = tile0;
+        const size_t lds = ldsNeed<1>(m_numLayers, nEmb);
+        bool dump = true;
+        if constexpr (F16) dump = q.dump != 0;
+        const int kind = q.condRawKind;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(ntiles), dim3(C::THREADS), lds, stream, q);
+            return hipGetLastError() == hipSuccess;
+        };
+        if constexpr (F16) {
+            if (!dump) {
+                if (kind == 2) return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, false, 2>);
+                if (kind == 1) return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, false, 1>);
+                return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, false, 0>);
+            }
+            if (kind == 2) return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, true, 2>);
+        }
+        if (kind == 1) return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, true, 1>);
+        return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, true, 0>);
     }
 };

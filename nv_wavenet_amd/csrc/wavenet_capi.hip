@@ -51,8 +51,8 @@ nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, in
         fprintf(stderr, "nvw_create: implementation %d out of range 0..4\n", implementation);
         return NULL;
     }
-    if (organisation < NVW_ORG_AUTO || organisation > NVW_ORG_WG3) {
-        fprintf(stderr, "nvw_create: organisation %d out of range 0..7\n", organisation);
+    if (organisation < NVW_ORG_AUTO || organisation > NVW_ORG_LAST) {
+        fprintf(stderr, "nvw_create: organisation %d out of range 0..%d\n", organisation, (int)NVW_ORG_LAST);
         return NULL;
     }
     nvw_engine* w = e->make(num_layers, max_dilation, batch_size, num_samples, implementation, tanh_embed, organisation);
@@ -84,15 +84,28 @@ void nvw_set_conditioning_n(nvw_engine* e, float* Lh, int num_samples) { e->setC
 void nvw_pack_conditioning(nvw_engine* e, float* Lh, int first_sample, int count, void* stream) {
     e->packConditioning(Lh, first_sample, count, (hipStream_t)stream);
 }
-void nvw_set_conditioning_direct(nvw_engine* e, float* Lh, int num_samples) { e->setConditioningDirect(Lh, num_samples); }
+void nvw_set_conditioning_direct(nvw_engine* e, float* Lh, int num_samples) { e->setConditioningDirect(Lh, num_samples, 32); }
+int nvw_set_conditioning_direct_t(nvw_engine* e, const void* Lh, int num_samples, int precision) {
+    if (precision != 32 && !(precision == 16 && e->precisionBits() == 16)) {
+        fprintf(stderr, "nvw_set_conditioning_direct_t: a %d-bit tensor cannot be read in place by an fp%d engine\n", precision,
+                e->precisionBits());
+        return 0;
+    }
+    e->setConditioningDirect(Lh, num_samples, precision);
+    return 1;
+}
 void nvw_set_selectors(nvw_engine* e, float* sel, int num_samples) { e->setSelectors(sel, num_samples); }
 unsigned nvw_chain_status(nvw_engine* e) { return e->chainStatus(); }
+unsigned nvw_chain_fallbacks(nvw_engine* e) { return e->chainFallbacks(); }
+unsigned nvw_chain_last_timeout(nvw_engine* e) { return e->chainLastTimeout(); }
+void nvw_set_chain_timeout_ms(nvw_engine* e, double ms) { e->setChainTimeoutMs(ms); }
 int nvw_run_range(nvw_engine* e, int init_sample, int count, int num_samples, int batch_size, void* stream) {
     return e->run_range(init_sample, count, num_samples, batch_size, (hipStream_t)stream) ? 1 : 0;
 }
 void nvw_reset_history(nvw_engine* e, void* stream) { e->resetHistory((hipStream_t)stream); }
 void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed) { e->setSelectorSeed(seed); }
-void nvw_set_audio_out(nvw_engine* e, short* pcmOut) { e->setAudioOut(pcmOut); }
+void nvw_set_audio_out(nvw_engine* e, short* pcmOut) { e->setAudioOut(pcmOut, 0); }
+void nvw_set_audio_out_n(nvw_engine* e, short* pcmOut, size_t elems) { e->setAudioOut(pcmOut, elems); }
 void nvw_kernel_info(nvw_engine* e, int batch_size, int dump_activations, char* buf, int buf_size) {
     e->kernelInfo(batch_size, dump_activations != 0, buf, buf_size);
 }

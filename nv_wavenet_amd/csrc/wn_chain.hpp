@@ -56,6 +56,7 @@ struct ChainParams {
     int lpc;                    // layers per layer stage (<= CCfg::LPC)
     int chains;                 // utterance tiles of this launch
     int tile0;                  // first tile (chains of one launch cover tiles tile0 .. tile0+chains-1)
+    long long timeoutTicks;     // bound of every spin, in ticks of the 100 MHz wall clock
 };
 
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
@@ -168,20 +169,19 @@ struct CCfg {
 #endif
 
 // ---- hand-off primitives -----------------------------------------------------------------------
-#ifndef WN_CHAIN_TIMEOUT_TICKS
-#define WN_CHAIN_TIMEOUT_TICKS 150000000LL     // 1.5 s of the 100 MHz wall clock
-#endif
+constexpr long long kChainTimeoutTicks = 150000000LL;     // default bound: 1.5 s of the 100 MHz wall clock
 
 struct Spin {
     gu32* status;
     long long t0;
     unsigned spins;
+    long long limit;
 };
 // false: give up (this wave timed out, or another one did)
 WN_DEV bool spin_more(Spin& s, unsigned code) {
     if ((++s.spins & 127u) == 0u) {
         if (__hip_atomic_load(s.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-        if ((long long)wall_clock64() - s.t0 > WN_CHAIN_TIMEOUT_TICKS) {
+        if ((long long)wall_clock64() - s.t0 > s.limit) {
             __hip_atomic_store(s.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -246,8 +246,8 @@ WN_DEV bool sweep_check(const unsigned long long (&q)[NT * 4], unsigned tag, flo
 // the same tiles, swept until every granule carries `tag`
 template <int NT, int NW>
 WN_DEV bool recv_tiles(const unsigned long long* mbox, int w, int lane, unsigned tag, floatx4 (&v)[NT], gu32* status,
-                       unsigned code) {
-    Spin s{status, (long long)wall_clock64(), 0u};
+                       unsigned code, long long limit) {
+    Spin s{status, (long long)wall_clock64(), 0u, limit};
     for (;;) {
         unsigned long long q[NT * 4];
         sweep_issue<NT, NW>(mbox, w, lane, q);
@@ -263,8 +263,8 @@ WN_DEV bool recv_tiles(const unsigned long long* mbox, int w, int lane, unsigned
 #endif
 template <int NT, int NW>
 WN_DEV bool recv_tiles_fast(const unsigned long long* mbox, int w, int lane, unsigned tag, floatx4 (&v)[NT], gu32* status,
-                            unsigned code) {
-    Spin s{status, (long long)wall_clock64(), 0u};
+                            unsigned code, long long limit) {
+    Spin s{status, (long long)wall_clock64(), 0u, limit};
     unsigned long long qa[NT * 4], qb[NT * 4];
     sweep_issue<NT, NW>(mbox, w, lane, qa);
     for (;;) {
@@ -281,11 +281,11 @@ WN_DEV bool recv_tiles_fast(const unsigned long long* mbox, int w, int lane, uns
 // Placement exchange at the start of a launch: every stage publishes the XCD it runs on and reads its
 // consumer's.  A speed matter only: the answer selects the store flavour of send_tiles, both are valid.
 WN_DEV unsigned my_xcd() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu; }   // HW_REG_XCC_ID[3:0]
-WN_DEV bool chain_place(unsigned long long* place, int mine, int consumer, gu32* status, bool& sameXcd) {
+WN_DEV bool chain_place(unsigned long long* place, int mine, int consumer, gu32* status, bool& sameXcd, long long limit) {
     gu64* g = (gu64*)place;
     const unsigned xcd = my_xcd();
     if (threadIdx.x == 0) __hip_atomic_store(g + mine, 0xC0DE00000000ull | xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    Spin s{status, (long long)wall_clock64(), 0u};
+    Spin s{status, (long long)wall_clock64(), 0u, limit};
     for (;;) {
         const unsigned long long c = __hip_atomic_load(g + consumer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((c >> 32) == 0xC0DEull) {
@@ -382,7 +382,7 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
     unsigned long long* const skout = xout + CC::XG;
     gu32* const status = (gu32*)cp.status;
     bool sameXcd = false;
-    if (!chain_place(cp.mail, chainIdx * cp.stages + stage, chainIdx * cp.stages + stage + 1, status, sameXcd)) return;
+    if (!chain_place(cp.mail, chainIdx * cp.stages + stage, chainIdx * cp.stages + stage + 1, status, sameXcd, cp.timeoutTicks)) return;
 
     // ---- gate and residual biases of the own layers -> LDS (the skip biases are added by the head) ----
     for (int i = tid; i < nl * 3 * R; i += C::THREADS)
@@ -456,16 +456,30 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
                 const int l = l0 + li;
                 const float* bl = biasLds + li * 3 * R;
                 const char* cp0 = condMine + ((size_t)t * L + l) * condStride;
-                if (p.condRaw) {
-                    // the caller's fp32 [sample][L][maxBatch][2R] tensor read in place: 4 channels of this lane's utterance
-                    // per gate tile, scaled and rounded like pack_cond_tiled_kernel would have (bit-identical to packed runs)
-                    const float* rb = p.condRaw + (((size_t)t * L + l) * p.maxBatch + ub) * (2 * R) + g * 4;
-                    frag raw[(F16 ? 2 : 1) * C::COND_FR];
+                if (p.condRawKind != 0) {
+                    // the caller's [sample][L][maxBatch][2R] tensor read in place: 4 channels of this lane's utterance per gate
+                    // tile, scaled and rounded like pack_cond_tiled_kernel would have (bit-identical to packed runs)
+                    const int tc = t < p.condSamples ? t : p.condSamples - 1;
+                    const size_t at = (((size_t)tc * L + l) * p.maxBatch + ub) * (2 * R) + g * 4;
+                    auto slotAt = [&](int it) { return (w + NW * (it >> 1) + (it & 1) * RT) * 16; };
+                    if (!F16 || p.condRawKind == 1) {
+                        const float* rb = (const float*)p.condRaw + at;
+                        frag raw[(F16 ? 2 : 1) * C::COND_FR];
 #pragma unroll
-                    for (int it = 0; it < 2 * HTW; it++)
-                        raw[it] = __builtin_bit_cast(frag, *(const floatx4*)(rb + (w + NW * (it >> 1) + (it & 1) * RT) * 16));
+                        for (int it = 0; it < 2 * HTW; it++) raw[it] = __builtin_bit_cast(frag, *(const floatx4*)(rb + slotAt(it)));
 #pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++) cd[0][k] = cond_frag<F16, true>(raw, k);
+                        for (int k = 0; k < C::COND_FR; k++) cd[0][k] = cond_frag<F16, 1>(raw, k);
+                    } else if constexpr (F16) {
+                        const _Float16* rb = (const _Float16*)p.condRaw + at;
+                        frag raw[C::COND_FR];
+#pragma unroll
+                        for (int k = 0; k < C::COND_FR; k++) {
+                            const half4 qa = *(const half4*)(rb + slotAt(2 * k)), qb = *(const half4*)(rb + slotAt(2 * k + 1));
+                            raw[k] = half8{qa[0], qa[1], qa[2], qa[3], qb[0], qb[1], qb[2], qb[3]};
+                        }
+#pragma unroll
+                        for (int k = 0; k < C::COND_FR; k++) cd[0][k] = cond_frag<F16, 2>(raw, k);
+                    }
                 } else {
 #pragma unroll
                     for (int k = 0; k < C::COND_FR; k++) cd[0][k] = *(const frag*)(cp0 + k * 1024 + laneOff);
@@ -507,7 +521,7 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
         // ---- the sample arrives: x_l0[t], this wave's tiles (fp32) ----------------------------------
         floatx4 x[HTW];
         WN_CT(1)
-        if (!recv_tiles_fast<HTW, NW>(xin, w, lane, tag, x, status, 0x100u + (unsigned)stage)) return;
+        if (!recv_tiles_fast<HTW, NW>(xin, w, lane, tag, x, status, 0x100u + (unsigned)stage, cp.timeoutTicks)) return;
         unsigned long long skq[STW * 4];
         WN_CT(2)
 #pragma unroll
@@ -590,7 +604,7 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
 #pragma unroll
             for (int i = 0; i < STW; i++) sk[i] = floatx4{0.f, 0.f, 0.f, 0.f};
         } else if (!sweep_check<STW>(skq, tag, sk)) {
-            if (!recv_tiles<STW, NW>(skin, w, lane, tag, sk, status, 0x200u + (unsigned)stage)) return;
+            if (!recv_tiles<STW, NW>(skin, w, lane, tag, sk, status, 0x200u + (unsigned)stage, cp.timeoutTicks)) return;
         }
         WN_CT(5)
 #pragma unroll
@@ -663,7 +677,7 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
     unsigned long long* const xout = boxes + ((size_t)chainIdx * cp.stages) * (CC::XG + CC::SG);   // stage 0
     gu32* const status = (gu32*)cp.status;
     bool sameXcd = false;
-    if (!chain_place(cp.mail, chainIdx * cp.stages + stage, chainIdx * cp.stages, status, sameXcd)) return;
+    if (!chain_place(cp.mail, chainIdx * cp.stages + stage, chainIdx * cp.stages, status, sameXcd, cp.timeoutTicks)) return;
 
     // ---- biases: sum of all skip biases (layer order, like wavenet_wg's running sums), Bzs, Bza ----
     for (int s0 = tid; s0 < S; s0 += C::THREADS) {
@@ -754,7 +768,7 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
         floatx4 sk[STW];
         WN_CT_DECL
         WN_CT(0)
-        if (!recv_tiles_fast<STW, NW>(skin, w, lane, tag, sk, status, 0x300u)) return;
+        if (!recv_tiles_fast<STW, NW>(skin, w, lane, tag, sk, status, 0x300u, cp.timeoutTicks)) return;
         WN_CT(1)
 #pragma unroll
         for (int i = 0; i < STW; i++) {
@@ -843,6 +857,30 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
     if (w == 0 && g == 0 && uvalid) {
         p.yInPrev[ub] = yPrev;
         p.yInCur[ub] = yCur;
+    }
+}
+
+// ---- behind a chain launch (nvWavenetInfer::launchChain) ---------------------------------------------------------
+// If the launch gave up (*status != 0: some spin ran into its bound because not every workgroup of the launch became
+// resident in time), put the dilation rings and the sample history of its tiles back to what they were when it started,
+// so that the gated wavenet_wg launch behind this kernel generates the same samples from the same state.
+static __global__ void chain_restore_kernel(const unsigned* status, uintx4* ring, const uintx4* ringShadow, size_t n16,
+                                            int* yInPrev, int* yInCur, const int* prevShadow, const int* curShadow, int nb) {
+    if (__builtin_nontemporal_load(status) == 0u) return;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < n16; i += step) ring[i] = ringShadow[i];
+    for (size_t i = i0; i < (size_t)nb; i += step) {
+        yInPrev[i] = prevShadow[i];
+        yInCur[i] = curShadow[i];
+    }
+}
+// ... and once that launch is done: status[1] := the code, status[2] += 1, status[0] := 0 (the next launch starts clean)
+static __global__ void chain_settle_kernel(unsigned* status) {
+    const unsigned s = status[0];
+    if (s != 0u) {
+        status[1] = s;
+        status[2] += 1u;
+        status[0] = 0u;
     }
 }
 

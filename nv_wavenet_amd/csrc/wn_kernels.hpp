@@ -39,8 +39,8 @@
 //   * Resident operands and the weight prefetch ring live in the accumulator file and are read in place by the
 //     MFMAs (agpr_pin); the conditioning comes either packed in fragment order or, RAW kernels, straight from the
 //     caller's fp32 tensor.
-//   * This header is the single-workgroup organisation and the device primitives; wn_stream.hpp (loader / consumer
-//     waves), wn_chain.hpp (multi-CU chain, resident weights) and wn_pipe.hpp (the chain kept full) build on it.
+//   * This header is the single-workgroup organisation and the device primitives; wn_chain.hpp (multi-CU chain,
+//     resident weights) builds on it.
 //
 // Layouts private to the engine (produced by the pack kernels at the bottom):
 //   fragment of an M x K weight matrix: 16 rows x (16*TPF) k-values, 64 lanes x 16 B:
@@ -67,6 +67,8 @@ namespace wn {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
 
 template <bool F16> struct Prec;
 template <> struct Prec<true> {
@@ -236,7 +238,11 @@ struct Params {
     const void* embPrev;     // [A][R] T_data
     const void* embCur;      // [A][R] T_data
     const void* cond;        // [sample][L][tile][wave][COND_FR] fragments
-    const float* condRaw;    // or (RAW kernels) the caller's fp32 [sample][L][maxBatch][2R] tensor, read in place
+    const void* condRaw;     // or (RAW kernels) the caller's [sample][L][maxBatch][2R] tensor, read in place: fp32 (RAW = 1)
+                             // or T_data = fp16 (RAW = 2, fp16 engine; the reference keeps m_Lh in T_data, nv_wavenet.cuh:326)
+    int condRawKind;         // 0: packed `cond`; 1: condRaw is fp32; 2: condRaw is fp16 (what the RAW template argument says, for
+                             // the kernels that choose at run time)
+    const unsigned* gate;    // when non-NULL: the launch does nothing unless *gate != 0 (fallback behind a wavenet_chain launch)
     const float* sel;        // [N][maxBatch] uniform draws
     void* ring;              // [tile][ringSlots][KF_R] fragments
     int maxDilation;         // dilation doubles per layer and restarts at 1 past this (nv_wavenet.cuh:110-111)
@@ -257,9 +263,9 @@ struct Params {
     int count;               // samples generated by this launch
     int ringSlots;           // sum of dilations
     int tiles;               // ceil(maxBatch/16): tile stride of cond / ring
+    int tileBase;            // first tile of this launch (workgroup b serves tiles tileBase + b*BT ...)
     int tanhEmbed;
     int dump;
-    int ntStream;            // non-temporal ring / conditioning traffic (large batches)
     int embLds;              // embedding tables held in LDS: 0 none, 1 current tap, 2 both
     int useRng;              // selectors drawn in-kernel (Philox4x32-10) instead of read from `sel`
     unsigned rngKey0, rngKey1;
@@ -369,6 +375,7 @@ WN_DEV void gate_stage(float a0, float a1, float b0, float b1, floatx2& ea, floa
     } else {
         if constexpr (ST == 0) ea = floatx2{__builtin_amdgcn_exp2f(a0), __builtin_amdgcn_exp2f(a1)};
         if constexpr (ST == 1) eb = floatx2{__builtin_amdgcn_exp2f(b0), __builtin_amdgcn_exp2f(b1)};
+#ifdef WN_GATE_PK
         if constexpr (ST == 2) {
             const floatx2 s = ea + 1.0f;        // (v_pk_add_f32)
             ra = floatx2{fast_rcp(s[0]), fast_rcp(s[1])};
@@ -377,6 +384,12 @@ WN_DEV void gate_stage(float a0, float a1, float b0, float b1, floatx2& ea, floa
             const floatx2 s = eb + 1.0f;
             rb = floatx2{fast_rcp(s[0]), fast_rcp(s[1])};
         }
+#else
+        // scalar adds: a packed-f32 VALU instruction issued beside MFMAs costs more than the two plain ones it replaces
+        // (MI355X_MICROARCH.md: +22..26 clk per pair)
+        if constexpr (ST == 2) ra = floatx2{fast_rcp(ea[0] + 1.0f), fast_rcp(ea[1] + 1.0f)};
+        if constexpr (ST == 3) rb = floatx2{fast_rcp(eb[0] + 1.0f), fast_rcp(eb[1] + 1.0f)};
+#endif
         if constexpr (ST == 4) h = floatx2{gate_finish(ra[0], rb[0]), gate_finish(ra[1], rb[1])};
     }
 #endif
@@ -417,16 +430,6 @@ WN_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: 
 #else
 WN_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
-
-// Streaming (non-temporal) access for data that is touched once per sample (conditioning) or
-// re-read only d samples later (dilation ring): keeps it from evicting the weight stream, which
-// every CU of an XCD re-reads from L2 each sample.
-// `nt` is wave-uniform: set by the host when the rings of all tiles cannot stay in L2 anyway.
-template <typename T> WN_DEV T ld_stream(const T* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
-template <typename T> WN_DEV void st_stream(T* p, T v, bool nt) {
-    if (nt) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
 
 // ---- LDS exchange of activations as B fragments -------------------------------------------
 // tile t of a vector, held in MFMA D layout (fp32), goes to its place in the fragment image
@@ -563,7 +566,6 @@ WN_DEV void gemm_ldsb(WStream<F16, PF, PIN>& ws, int pos0, const char* cur, cons
 // the group: 52 -> 32 waits per two layers).  Measured slower (C3 fp16, two tiles: 30 vs 28 us per sample): a group
 // waits for its youngest fragment before its first MFMA, which shortens the 9-fragment lookahead by G-1, and at
 // ~700 clk per L2 load the stream has no slack for that.
-typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #ifndef WN_TAKE_G
 #define WN_TAKE_G 1          // fragments taken (waited for) together: see take_group
@@ -788,16 +790,33 @@ WN_DEV int softmax_pick(const float* lrow, int sq, int lane, float sel, float (&
 // conditioning fragment k of a tile from its registers: the packed fragment itself, or (fp16 engine reading the
 // caller's fp32 tensor in place) built from the two fp32 quads of the gate pair -- scaled by the gate's pre-scale and
 // rounded to fp16 exactly like pack_cond_tiled_kernel does
-template <bool F16, bool RAW, int CR> WN_DEV typename Prec<F16>::frag cond_frag(const typename Prec<F16>::frag (&c)[CR], int k) {
-    if constexpr (RAW && F16) {
+// fp16(value * scale) of a pair of values into one packed register, one v_fma_mix per value: the product is formed
+// in fp32 (from fp32 or from fp16 sources, converted exactly) and rounded to fp16 by the instruction.  The pack kernel and
+// both in-place paths use THESE functions, so the three ways of handing over the conditioning agree bit for bit.
+WN_DEV unsigned scale_pair_f32(float a, float b, float sc) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "s"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(b), "s"(sc));
+    return d;
+}
+WN_DEV unsigned scale_pair_f16(unsigned h2, float sc) {      // h2: two fp16 values
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "s"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(h2), "s"(sc));
+    return d;
+}
+// RAW = 2: the caller's tensor is fp16 already; register k holds the two raw quads of the gate pair (tanh tile | sigmoid tile)
+template <bool F16, int RAW, int CR> WN_DEV typename Prec<F16>::frag cond_frag(const typename Prec<F16>::frag (&c)[CR], int k) {
+    if constexpr (RAW == 1 && F16) {
         const floatx4 a = __builtin_bit_cast(floatx4, c[2 * k]), b = __builtin_bit_cast(floatx4, c[2 * k + 1]);
-        half8 f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            f[r] = (_Float16)(a[r] * gate_prescale<true>(false));
-            f[4 + r] = (_Float16)(b[r] * gate_prescale<true>(true));
-        }
-        return f;
+        const float st = gate_prescale<true>(false), ss = gate_prescale<true>(true);
+        return __builtin_bit_cast(half8, uintx4{scale_pair_f32(a[0], a[1], st), scale_pair_f32(a[2], a[3], st),
+                                                scale_pair_f32(b[0], b[1], ss), scale_pair_f32(b[2], b[3], ss)});
+    } else if constexpr (RAW == 2 && F16) {
+        const uintx4 q = __builtin_bit_cast(uintx4, c[k]);
+        const float st = gate_prescale<true>(false), ss = gate_prescale<true>(true);
+        return __builtin_bit_cast(half8, uintx4{scale_pair_f16(q[0], st), scale_pair_f16(q[1], st), scale_pair_f16(q[2], ss),
+                                                scale_pair_f16(q[3], ss)});
     } else {
         return c[k];
     }
@@ -812,10 +831,12 @@ template <bool F16, bool RAW, int CR> WN_DEV typename Prec<F16>::frag cond_frag(
 // DUMP: the variant that can write the activation dump of the launch's last sample (getXtOut ...).
 // Production launches (dumpActivations = false) use DUMP = false: even as a never-taken branch the
 // dump costs accumulator read-outs in every layer (35.6 vs 39.0 us per sample at batch 8192).
-// RAW: the conditioning is read in place from the caller's fp32 [N][L][B][2R] tensor (Params::condRaw: no packed copy
-// exists); each lane loads the 4 consecutive channels of its utterance per gate tile (16 bytes) and, in the fp16 engine,
-// scales and rounds them exactly as pack_cond_tiled_kernel would have, so packed and in-place runs are bit-identical.
-template <bool F16, int R, int S, int A, int BT, bool EMBLDS, bool DUMP = true, bool RAW = false>
+// RAW: the conditioning is read in place from the caller's [N][L][B][2R] tensor (Params::condRaw: no packed copy
+// exists), fp32 (RAW = 1) or, fp16 engine, T_data = fp16 (RAW = 2: half the bytes; the reference keeps its conditioning in
+// T_data, nv_wavenet.cuh:326); each lane loads the 4 consecutive channels of its utterance per gate tile (16 / 8 bytes) and, in
+// the fp16 engine, scales and rounds them exactly as pack_cond_tiled_kernel would have, so packed and in-place runs are
+// bit-identical (for an fp16 tensor: identical to packing its values).
+template <bool F16, int R, int S, int A, int BT, bool EMBLDS, bool DUMP = true, int RAW = 0>
 __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_wg(const Params p) {
     using C = Cfg<F16, R, S, A, BT>;
     using P = Prec<F16>;
@@ -836,12 +857,15 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     char* const xpbuf = lds + C::OFF_XP;
     float* const biasLds = (float*)(lds + C::LDS_FIXED);
 
+    static_assert(RAW == 0 || RAW == 1 || (RAW == 2 && F16), "RAW: 0 packed, 1 fp32 in place, 2 fp16 in place (fp16 engine)");
+    if (p.gate != nullptr && __builtin_nontemporal_load(p.gate) == 0u) return;   // (a fallback launch that is not needed)
+
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
     const int L = p.numLayers;
-    const int tile0 = blockIdx.x * BT;
+    const int tile0 = p.tileBase + blockIdx.x * BT;
 
     // utterance of this lane in its MFMA role (column j of tile bt)
     int ub[BT];
@@ -874,7 +898,6 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     }
 
     const unsigned laneOff = (unsigned)lane * 16u;
-    const bool nt = p.ntStream != 0;
     // wave-uniform byte bases (SGPRs); per-lane part is laneOff
     const char* const wbase = (const char*)p.wblob + (size_t)w * C::waveStreamFrags(L) * 1024;
     const char* const whead = wbase + C::headOffsetFrags(L) * 1024;
@@ -909,7 +932,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 
     // ---- prime the weight ring ----------------------------------------------------------------
     // (two tiles per workgroup reading the conditioning in place need the accumulator file as spill space: ring in VGPRs)
-    constexpr bool ws_pin = F16 && !(RAW && BT == 2);
+    constexpr bool ws_pin = F16 && !(RAW == 1 && BT == 2);
     WStream<F16, PF, ws_pin> ws;
     const rsrc_t rsW = make_rsrc(wbase);      // the wave's weight stream as a buffer: fragment positions become SGPR offsets
 #pragma unroll
@@ -933,7 +956,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     // the load issued one layer earlier to have landed, i.e. halve the prefetch distance).
     frag xpA[BT][XPW], xpB[BT][XPW];            // layers of even / odd parity
     // conditioning registers per tile: COND_FR packed fragments, or (fp16, in-place) one fp32 quad per gate tile
-    constexpr int CR = (RAW && F16) ? 2 * C::COND_FR : C::COND_FR;
+    constexpr int CR = (RAW == 1 && F16) ? 2 * C::COND_FR : C::COND_FR;
     frag cdA[BT][CR], cdB[BT][CR];
     // per-(sample,layer) strides in bytes; everything here is wave-uniform (SALU)
     const size_t condStride = (size_t)p.tiles * NW * C::COND_FR * 1024;            // one (sample,layer) row
@@ -950,12 +973,24 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     const rsrc_t rsRing = make_rsrc(ringMine);
     const unsigned ringTileB = (unsigned)ringTile;
     const char* condNext = condMine + (size_t)p.initSample * L * condStride;
+    // in-place conditioning: one row = [maxBatch][2R] source elements; per-lane part of the address (utterance, channel quad)
+    constexpr unsigned RAWE = RAW == 2 ? 2u : 4u;                                   // bytes per source element
+    const size_t rawRow = (size_t)p.maxBatch * (2 * R) * RAWE;
+    unsigned rawOff[BT];
+#pragma unroll
+    for (int bt = 0; bt < BT; bt++) rawOff[bt] = ((unsigned)ub[bt] * (unsigned)(2 * R) + (unsigned)g * 4u) * RAWE;
     auto prefetch = [&](int tn, int ln, Dil dl, frag (&xd)[BT][XPW], frag (&cdd)[BT][CR]) {
         if (ln >= L) { ln -= L; tn += 1; }
+#ifdef WN_ABL_HOTLOADS      // timing experiment: taps and conditioning always from the same (L2-resident) addresses
+        const unsigned slot = (unsigned)(dl.off & 1);
+        const unsigned rp0 = slot * (unsigned)(KF_R * 1024);
+        const rsrc_t rsCond = make_rsrc(condNext);
+#else
         const unsigned slot = (unsigned)(dl.off + (tn & (dl.d - 1)));
         const unsigned rp0 = slot * (unsigned)(KF_R * 1024);
         const rsrc_t rsCond = make_rsrc(condNext);
         condNext += condStride;
+#endif
 #ifndef WN_ABL_NOXP
 #pragma unroll
         for (int i = 0; i < XPW; i++) {
@@ -977,14 +1012,21 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 for (int e = 0; e < P::EPL; e++) xd[bt][i][e] = (elem)(float)(tn + i);
 #endif
 #ifndef WN_ABL_NOCOND
-            if constexpr (RAW) {
+            if constexpr (RAW != 0) {
                 // gate slot it = 0 .. 2*HTW-1 -> tile w + NW*(it>>1) (+RT for the sigmoid half): 4 channels of this lane's utterance
                 const int tc = tn < p.condSamples ? tn : p.condSamples - 1;      // (the read-ahead past the last sample is never used)
-                const float* rb = p.condRaw + (((size_t)tc * L + ln) * p.maxBatch + ub[bt]) * (2 * R) + g * 4;
+                const rsrc_t rsRaw = make_rsrc((const char*)p.condRaw + ((size_t)tc * L + ln) * rawRow);
+                auto slotOff = [&](int it) { return (unsigned)((w + NW * (it >> 1) + (it & 1) * RT) * 16) * RAWE; };
+                if constexpr (RAW == 1) {
 #pragma unroll
-                for (int it = 0; it < 2 * HTW; it++) {
-                    const floatx4 q = ld_stream((const floatx4*)(rb + (w + NW * (it >> 1) + (it & 1) * RT) * 16), nt);
-                    cdd[bt][it] = __builtin_bit_cast(frag, q);
+                    for (int it = 0; it < 2 * HTW; it++) cdd[bt][it] = buf_load<frag, 2>(rsRaw, rawOff[bt], slotOff(it));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < HTW; k++) {      // (fp16: COND_FR = HTW; one register = the tanh and the sigmoid quad)
+                        const uintx2 qa = __builtin_amdgcn_raw_buffer_load_b64(rsRaw, rawOff[bt], slotOff(2 * k), 2);
+                        const uintx2 qb = __builtin_amdgcn_raw_buffer_load_b64(rsRaw, rawOff[bt], slotOff(2 * k + 1), 2);
+                        cdd[bt][k] = __builtin_bit_cast(frag, uintx4{qa[0], qa[1], qb[0], qb[1]});
+                    }
                 }
             } else {
 #pragma unroll
@@ -1561,15 +1603,14 @@ __global__ void convert_kernel(typename Prec<F16>::elem* __restrict__ dst, const
 }
 
 // conditioning: fp32 [rows = samples*L][maxBatch][2R] -> T_data fragments, gate rows pre-scaled.
-//   STREAM = false (wavenet_wg / wavenet_chain): [rows][tiles][wave][COND_FR][lane][EPL];
+//   [rows][tiles][wave][COND_FR][lane][EPL];
 //       fragment c, element e of wave w: gate slot it = c*TPF + (e>>2) -> tile = w + NW*(it>>1) + (it&1)*RT
-//   STREAM = true (wavenet_stream): [rows][tiles][2R/(16*TPF)][lane][EPL], tiles in natural order
 // One workgroup per (row, tile of 16 utterances): the 16 x 2R fp32 source block is contiguous (8 KB at
 // R = 64) and is read with coalesced 16-byte loads into LDS; the 2R*16 destination elements are
 // contiguous too and are written as one 16-byte piece per thread.  (The first version gathered one
 // scalar per thread straight from global memory: 2.2-4.5x read amplification, 19 ms for 256 samples x
 // 8192 utterances; this one moves source + destination bytes once.)
-template <bool F16, int R, bool STREAM>
+template <bool F16, int R>
 __global__ __launch_bounds__(256) void pack_cond_tiled_kernel(typename Prec<F16>::elem* __restrict__ dst,
                                                               const float* __restrict__ src, size_t rows, int maxBatch,
                                                               int tiles) {
@@ -1599,29 +1640,26 @@ __global__ __launch_bounds__(256) void pack_cond_tiled_kernel(typename Prec<F16>
             frag o;
 #pragma unroll
             for (int q = 0; q < EPL / 4; q++) {
-                int tile16;
-                if (STREAM) tile16 = fr * TPF + q;
-                else {
-                    const int w = fr / COND_FR, c = fr % COND_FR;
-                    const int it = c * TPF + q;
-                    tile16 = w + NW * (it >> 1) + (it & 1) * RT;
-                }
+                const int w = fr / COND_FR, c = fr % COND_FR;
+                const int it = c * TPF + q;
+                const int tile16 = w + NW * (it >> 1) + (it & 1) * RT;
                 const int ch = tile16 * 16 + g * 4;
                 const floatx4 v = *(const floatx4*)(blk + j * LROWF + ch);
                 const float sc = gate_prescale<F16>(ch >= R);
+                if constexpr (F16) {
+                    const unsigned lo = scale_pair_f32(v[0], v[1], sc), hi = scale_pair_f32(v[2], v[3], sc);
+                    const half4 h = __builtin_bit_cast(half4, uintx2{lo, hi});
 #pragma unroll
-                for (int r = 0; r < 4; r++) o[q * 4 + r] = (elem)(v[r] * sc);
+                    for (int r = 0; r < 4; r++) o[q * 4 + r] = h[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[q * 4 + r] = (elem)(v[r] * sc);
+                }
             }
             __builtin_nontemporal_store(o, (frag*)(d + (size_t)pi * EPL));
         }
         __syncthreads();
     }
-}
-
-// Bh (2R gate biases of one layer, fp32, in place): the pre-scaling of gate1()
-template <bool F16> __global__ void scale_gate_bias_kernel(float* bh, int R) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * R; i += gridDim.x * blockDim.x)
-        bh[i] *= gate_prescale<F16>(i >= R);
 }
 
 static __global__ void silence_kernel(int* yInPrev, int* yInCur, int n) {

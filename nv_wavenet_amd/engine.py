@@ -24,15 +24,13 @@ class Impl:
 class Org:
     """Kernel organisations (nvwOrganisation in nv_wavenet.hpp; last argument of nvw_create_ex)."""
     AUTO = 0        # from the Implementation value and the batch size
-    WG = 1          # wn::wavenet_wg, 1 or 2 tiles of 16 utterances per workgroup by batch size
+    WG = 1          # wn::wavenet_wg, 1, 2 or 3 tiles of 16 utterances per workgroup by batch size
     WG1 = 2
     WG2 = 3
-    STREAM = 4      # wn::wavenet_stream (loader / consumer waves)
+    WG3 = 4         # three tiles per workgroup (fp16, R <= 64; else two)
     CHAIN = 5       # wn::wavenet_chain: multi-CU, weights resident, fewest CUs
     CHAIN1 = 6      # wn::wavenet_chain, one layer per CU
-    PIPE = 7        # wn::wavenet_pipe: the chain kept full (throughput, large batches)
-    WG3 = 8         # wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64; else two)
-    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "stream": 4, "chain": 5, "chain1": 6, "pipe": 7, "wg3": 8}
+    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6}
 
 
 def supported_configs():
@@ -64,8 +62,8 @@ class WavenetEngine:
         self.precision = precision
         if isinstance(organisation, str) or organisation is None:
             organisation = Org.BY_NAME[organisation]
-        if organisation not in range(9):
-            raise ValueError("organisation must be 0..8")
+        if organisation not in range(7):
+            raise ValueError("organisation must be 0..6")
         self._h = lib.nvw_create_ex(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
                                     1 if tanhEmbed else 0, organisation)
         if not self._h:
@@ -105,6 +103,7 @@ class WavenetEngine:
         n = ns * self.numLayers * self.maxBatch * 2 * self.R
         assert (Lh.numel() if hasattr(Lh, "numel") else Lh.size) == n, "Lh has the wrong size"
         assert (sel.numel() if hasattr(sel, "numel") else sel.size) == ns * self.maxBatch
+        self._cond_keep = None
         lib.nvw_set_inputs_n(self._h, addr(Lh), addr(sel), ns)
 
     # ---- beyond the reference class (include/nv_wavenet_c.h, "extensions") ---------------------
@@ -115,18 +114,23 @@ class WavenetEngine:
         assert 0 < ns <= self.maxSamples
         n = ns * self.numLayers * self.maxBatch * 2 * self.R
         assert (Lh.numel() if hasattr(Lh, "numel") else Lh.size) == n, "Lh has the wrong size"
+        self._cond_keep = None
         lib.nvw_set_conditioning_n(self._h, addr(Lh), ns)
 
     def setConditioningDirect(self, Lh, numSamples=None):
-        """Device-resident conditioning consumed in place: Lh is a CUDA fp32 tensor [numSamples][L][maxBatch][2R]; no
-        packed copy is made and the kernels read it directly.  The tensor is kept referenced here until the next
-        set* call; do not modify it while runs are in flight."""
-        Lh = _f32(Lh)
-        assert hasattr(Lh, "data_ptr") and Lh.is_cuda, "setConditioningDirect takes device tensors"
+        """Device-resident conditioning consumed in place: Lh is a CUDA tensor [numSamples][L][maxBatch][2R], float32 or
+        -- fp16 engines -- float16 (the engine's T_data: half the bytes); no packed copy is made and the kernels read it
+        directly.  The tensor is kept referenced here until the next conditioning call; do not modify it while runs
+        are in flight."""
+        import torch
+        assert hasattr(Lh, "data_ptr") and Lh.is_cuda and Lh.is_contiguous(), "setConditioningDirect takes contiguous device tensors"
+        bits = {torch.float32: 32, torch.float16: 16}.get(Lh.dtype)
+        if bits is None or (bits == 16 and self.precision != 16):
+            raise TypeError("an fp%d engine cannot read a %s tensor in place" % (self.precision, Lh.dtype))
         ns = self.maxSamples if numSamples is None else int(numSamples)
         assert Lh.numel() == ns * self.numLayers * self.maxBatch * 2 * self.R, "Lh has the wrong size"
         self._cond_keep = Lh
-        lib.nvw_set_conditioning_direct(self._h, addr(Lh), ns)
+        assert lib.nvw_set_conditioning_direct_t(self._h, addr(Lh), ns, bits)
 
     def setSelectors(self, outputSelectors, numSamples=None):
         """The selector half of setInputs: [numSamples][maxBatch] uniform draws; conditioning and history untouched."""
@@ -141,6 +145,7 @@ class WavenetEngine:
         Lh = _f32(Lh)
         assert hasattr(Lh, "data_ptr") and Lh.is_cuda, "packConditioning takes device tensors"
         assert Lh.numel() == count * self.numLayers * self.maxBatch * 2 * self.R
+        self._cond_keep = None
         lib.nvw_pack_conditioning(self._h, addr(Lh), int(firstSample), int(count), stream)
 
     def run_partial_chunk(self, init_sample, count, num_samples, batch_size, stream=None):
@@ -151,8 +156,18 @@ class WavenetEngine:
         lib.nvw_reset_history(self._h, stream)
 
     def chainStatus(self):
-        """0 when every multi-CU launch ran to completion (synchronises), else the first time-out code."""
+        """0, or the code of a multi-CU launch that gave up and could not be re-run (synchronises)."""
         return int(lib.nvw_chain_status(self._h))
+
+    def chainFallbacks(self):
+        """Multi-CU launches that gave up (not all workgroups resident in time) and were re-run on wavenet_wg."""
+        return int(lib.nvw_chain_fallbacks(self._h))
+
+    def chainLastTimeout(self):
+        return int(lib.nvw_chain_last_timeout(self._h))
+
+    def setChainTimeoutMs(self, ms):
+        lib.nvw_set_chain_timeout_ms(self._h, float(ms))
 
     def kernelInfo(self, batch_size=None, dumpActivations=False):
         """The device code run(n, batch_size, ..., dumpActivations) launches (kernel + template arguments)."""
@@ -176,9 +191,11 @@ class WavenetEngine:
             else:
                 assert pcmOut.dtype == np.int16 and pcmOut.flags["C_CONTIGUOUS"]
             n = pcmOut.numel() if hasattr(pcmOut, "numel") else pcmOut.size
-            assert n >= self.maxBatch, "pcmOut must hold [batch][num_samples] int16"
-        self._pcm_keep = pcmOut
-        lib.nvw_set_audio_out(self._h, addr(pcmOut) if pcmOut is not None else None)
+            self._pcm_keep = pcmOut
+            lib.nvw_set_audio_out_n(self._h, addr(pcmOut), n)   # every run call checks batch * num_samples <= n
+        else:
+            self._pcm_keep = None
+            lib.nvw_set_audio_out(self._h, None)
 
     # ---- run --------------------------------------------------------------------------------
     def _yout(self, yOut, need=None):

@@ -105,14 +105,15 @@ class NVWaveNet:
 
 
 def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, cond_weight, cond_bias, n_layers,
-                   layout="CBLN"):
+                   layout="CBLN", dtype=None):
     """WaveNet.get_cond_input (pytorch/wavenet.py:190-202) as a function of the module's tensors,
     run wherever `features` lives (the GPU): ConvTranspose1d upsampling, trimming of the
     (kernel - stride) transposed-convolution tail, the 1x1 `cond_layers` convolution.
     features [B][n_cond][frames]; upsample_weight [n_cond][n_cond][kernel]; cond_weight
     [2R*n_layers][n_cond][1].  layout "CBLN" returns the reference's 2R x batch x layers x samples
     view; "NLBC" returns the engine's own [samples][layers][batch][2R] contiguous tensor, which
-    NVWaveNetEngine.infer takes without a further permute/copy."""
+    NVWaveNetEngine.infer takes without a further permute/copy.  dtype=torch.float16 emits the conditioning in the fp16
+    engine's T_data (rounded once, here), which that engine then reads in place at half the bytes."""
     import torch.nn.functional as F
     x = F.conv_transpose1d(features, upsample_weight, upsample_bias, stride=upsample_stride)
     cutoff = upsample_weight.size(2) - upsample_stride
@@ -121,9 +122,11 @@ def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, co
     x = F.conv1d(x, cond_weight, cond_bias)
     x = x.view(x.size(0), n_layers, -1, x.size(2))          # [B][L][2R][N]
     if layout == "CBLN":
-        return x.permute(2, 0, 1, 3)
+        x = x.permute(2, 0, 1, 3)
+        return x if dtype is None else x.to(dtype)
     assert layout == "NLBC"
-    return x.permute(3, 1, 0, 2).contiguous()
+    x = x.permute(3, 1, 0, 2)
+    return (x if dtype is None else x.to(dtype)).contiguous()
 
 
 class NVWaveNetEngine(NVWaveNet):
@@ -192,141 +195,24 @@ class NVWaveNetEngine(NVWaveNet):
             assert layout == "NLBC" and cond_input.is_contiguous() and \
                 tuple(cond_input.size()[1::2]) == (self.num_layers, 2 * self.R)
         sample_count, batch_size = cond_input.size(0), cond_input.size(2)
-        cond_input = cond_input.float()
+        # the conditioning lives where the model lives (a host tensor is uploaded once, like the reference's setInputs
+        # does); an fp16 engine reads an fp16 tensor as it is, everything else is consumed as fp32
+        dev = self.conv_out.device
+        keep_half = self.precision == 16 and cond_input.dtype == torch.float16
+        cond_input = cond_input.to(device=dev, dtype=torch.float16 if keep_half else torch.float32).contiguous()
         e = self._engine(batch_size, sample_count, implementation)
-        # everything below is ordered on the caller's current stream: the tensors above were produced on it,
-        # the engine's launches go to it, and the results are consumed on it
-        stream = torch.cuda.current_stream(cond_input.device)
+        # everything below is ordered on the caller's current stream of that device: the tensors above were produced
+        # on it, the engine's launches go to it, and the results are consumed on it
+        stream = torch.cuda.current_stream(dev)
         sptr = stream.cuda_stream
-        # device conditioning is consumed in place from this tensor (no packed copy; the engine itself falls back to
-        # packing where an organisation has no in-place path); it stays referenced until the run below has completed
-        stream.synchronize()            # (the engine's own uploads run on its upload stream)
-        if cond_input.is_cuda:
-            e.setConditioningDirect(cond_input, sample_count)
-        else:
-            e.setConditioning(cond_input, sample_count)
+        stream.synchronize()                # (the engine's own uploads run on its upload stream)
+        # consumed in place from this tensor: no packed copy; it stays referenced until the run below has completed
+        e.setConditioningDirect(cond_input, sample_count)
         if seed is None:
-            sel = torch.rand(sample_count, batch_size, dtype=torch.float32, device=cond_input.device,
-                             generator=generator)
+            sel = torch.rand(sample_count, batch_size, dtype=torch.float32, device=dev, generator=generator)
             stream.synchronize()
             e.setSelectors(sel, sample_count)
         else:
-            e.setSelectorSeed(seed)
-        samples = torch.zeros(batch_size, sample_count, dtype=torch.int32, device=cond_input.device)
-        nv_wavenet_ext.infer(samples, sample_count, batch_size, self.embedding_prev, self.embedding_curr,
-                             self.conv_out, self.conv_end, cond_input, self.num_layers, self.use_embed_tanh,
-                             self.max_dilation, implementation, self.layers)
-        return samples
-
-
-def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, cond_weight, cond_bias, n_layers,
-                   layout="CBLN"):
-    """WaveNet.get_cond_input (pytorch/wavenet.py:190-202) as a function of the module's tensors,
-    run wherever `features` lives (the GPU): ConvTranspose1d upsampling, trimming of the
-    (kernel - stride) transposed-convolution tail, the 1x1 `cond_layers` convolution.
-    features [B][n_cond][frames]; upsample_weight [n_cond][n_cond][kernel]; cond_weight
-    [2R*n_layers][n_cond][1].  layout "CBLN" returns the reference's 2R x batch x layers x samples
-    view; "NLBC" returns the engine's own [samples][layers][batch][2R] contiguous tensor, which
-    NVWaveNetEngine.infer takes without a further permute/copy."""
-    import torch.nn.functional as F
-    x = F.conv_transpose1d(features, upsample_weight, upsample_bias, stride=upsample_stride)
-    cutoff = upsample_weight.size(2) - upsample_stride
-    if cutoff > 0:
-        x = x[:, :, :-cutoff]
-    x = F.conv1d(x, cond_weight, cond_bias)
-    x = x.view(x.size(0), n_layers, -1, x.size(2))          # [B][L][2R][N]
-    if layout == "CBLN":
-        return x.permute(2, 0, 1, 3)
-    assert layout == "NLBC"
-    return x.permute(3, 1, 0, 2).contiguous()
-
-
-class NVWaveNetEngine(NVWaveNet):
-    """The same wrapper with the engine kept alive: the reference rebuilds
-    its nvWavenetInfer object and re-uploads every weight on each infer() (wavenet_infer.cu:124-143).
-    Here the weights are uploaded once per (batch, samples) engine, R/S/A are taken from the
-    tensors (any instantiation in the build, fp32 or fp16), conditioning may already be in the
-    engine's layout on the device, selectors can be drawn in-kernel from a seed, and int16 audio
-    can be returned beside the indices."""
-
-    def __init__(self, *args, precision=32, **kwargs):
-        self.precision = precision
-        self._engines = {}
-        super().__init__(*args, **kwargs)
-
-    def _compiled_dims(self, embedding_prev, conv_out_weight):
-        from .engine import supported_configs
-        dims = (embedding_prev.size(1), conv_out_weight.size(1), embedding_prev.size(0))
-        assert dims + (self.precision,) in set(supported_configs()), \
-            "no engine for R,S,A,precision = %s in this build" % (dims + (self.precision,),)
-        return dims
-
-    # engines are kept per (batch, sample CAPACITY, implementation): the capacity is the sample count rounded up
-    # to a bucket, and an utterance shorter than the capacity runs as a prefix (conditioning, selectors and
-    # samples are sample-major), so a new utterance length neither rebuilds the engine nor re-uploads the
-    # weights.  At most MAX_ENGINES stay alive (least recently used goes first).
-    BUCKET = 4096
-    MAX_ENGINES = 4
-
-    def _engine(self, batch_size, sample_count, implementation):
-        from .engine import WavenetEngine
-        capacity = -(-sample_count // self.BUCKET) * self.BUCKET
-        key = (batch_size, capacity, int(implementation))
-        e = self._engines.pop(key, None)
-        if e is None:
-            while len(self._engines) >= self.MAX_ENGINES:
-                old_key = next(iter(self._engines))
-                self._engines.pop(old_key).close()
-            e = WavenetEngine(self.R, self.S, self.A, self.num_layers, self.max_dilation, batch_size, capacity,
-                              impl=int(implementation), tanhEmbed=bool(self.use_embed_tanh), precision=self.precision)
-            f = lambda t: t.float().contiguous()
-            e.setEmbeddings(f(self.embedding_prev), f(self.embedding_curr))
-            for l in range(self.num_layers):
-                e.setLayerWeights(l, *[f(t) for t in self.layers[7 * l:7 * l + 7]])
-            zeros = torch.zeros(self.A, dtype=torch.float32, device=self.conv_out.device)
-            e.setOutWeights(f(self.conv_out), zeros, f(self.conv_end), zeros)   # wavenet_infer.cu:75-82
-        self._engines[key] = e          # (re-)inserted last: most recently used
-        return e
-
-    def close(self):
-        for e in self._engines.values():
-            e.close()
-        self._engines = {}
-
-    def infer(self, cond_input, implementation=Impl.AUTO, seed=None, return_audio=False, layout="CBLN",
-              generator=None):
-        """cond_input: 2R x batch x layers x samples (layout "CBLN", the reference's) or
-        [samples][layers][batch][2R] contiguous (layout "NLBC", used in place).
-        seed: int -> selectors drawn in-kernel by Philox4x32-10; None -> torch.rand on the device.
-        Returns int32 [batch][samples] (and int16 audio [batch][samples] when return_audio)."""
-        if layout == "CBLN":
-            assert tuple(cond_input.size()[0:3:2]) == (2 * self.R, self.num_layers), \
-                "Inputs are channels x batch x num_layers x samples; got %s" % (tuple(cond_input.size()),)
-            cond_input = column_major(cond_input.contiguous())
-        else:
-            assert layout == "NLBC" and cond_input.is_contiguous() and \
-                tuple(cond_input.size()[1::2]) == (self.num_layers, 2 * self.R)
-        sample_count, batch_size = cond_input.size(0), cond_input.size(2)
-        cond_input = cond_input.float()
-        e = self._engine(batch_size, sample_count, implementation)
-        # everything below is ordered on the caller's current stream: the tensors above were produced on it,
-        # the engine's launches go to it, and the results are consumed on it
-        stream = torch.cuda.current_stream(cond_input.device)
-        sptr = stream.cuda_stream
-        # the conditioning is consumed in place from this tensor (no packed copy; the engine falls back to packing
-        # where an organisation has no in-place path); it stays referenced until the run below has completed
-        if seed is None:
-            sel = torch.rand(sample_count, batch_size, dtype=torch.float32, device=cond_input.device,
-                             generator=generator)
-            stream.synchronize()        # the engine's uploads run on its own stream
-            e.setInputs(cond_input[:1].contiguous().expand(sample_count, -1, -1, -1).contiguous() if False else cond_input, sel, sample_count) \
-                if not cond_input.is_cuda else (e.setSelectors(sel, sample_count), e.setConditioningDirect(cond_input, sample_count))
-        else:
-            stream.synchronize()
-            if cond_input.is_cuda:
-                e.setConditioningDirect(cond_input, sample_count)
-            else:
-                e.setConditioning(cond_input, sample_count)
             e.setSelectorSeed(seed)
         samples = torch.zeros(batch_size, sample_count, dtype=torch.int32, device=cond_input.device)
         audio = torch.zeros(batch_size, sample_count, dtype=torch.int16, device=cond_input.device) \
@@ -336,5 +222,5 @@ class NVWaveNetEngine(NVWaveNet):
         ok = e.run(sample_count, batch_size, samples, bspb, False, sptr)
         stream.synchronize()
         e.setAudioOut(None)
-        assert ok and e.chainStatus() == 0, "nvWavenetInfer::run failed"
+        assert ok and e.chainStatus() == 0, "nvWavenetInfer::run failed"   # (a multi-CU launch that gave up was re-run on wavenet_wg)
         return (samples, audio) if return_audio else samples

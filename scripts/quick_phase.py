@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase shader-clock breakdown of wavenet_wg / wavenet_stream (needs the WN_TIMING experiment build via NVW_LIB).
-usage: quick_phase.py [batch] [samples] [organisation: 2 = wg one tile (default), 3 = wg two tiles, 4 = stream]"""
+usage: quick_phase.py [batch] [samples] [organisation: 2 = wg one tile (default), 3 = two tiles, 4 = three tiles]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,8 +14,7 @@ Lh, sel = bench.device_inputs(B, N, 1)
 e.setInputs(Lh, sel)
 ms = e.time_runs(1, N, B)
 P = e.getP().reshape(-1)[:12]
-names_stream = ["embed+skipinit", "layer top: bfrags/ring st/prefetch/acc init", "prev+cur gemm", "cond add + gate valu", "res gemm", "skip gemm", "dump/loop", "head gemms", "softmax+pick", "-", "-", "sel load"]
-names = names_stream if ORG == 4 else ["embed+barrier", "xb read + tap gemm (prev layer's tail)", "cur gemm+ring st+prefetch", "gate || skip gemm + publish tap", "barrier h",
+names = ["embed+barrier", "xb read + tap gemm (prev layer's tail)", "cur gemm+ring st+prefetch", "gate || skip gemm + publish tap", "barrier h",
          "hb/xp read+res gemm+put x", "cond mfma(+dump)", "barrier x", "head gemms", "pad takes+barrier", "softmax+ybarrier", "sel load"]
 tot = P.sum()
 print("B=%d N=%d: %.2f us/sample; wave0 clock total %.0f per sample (=%.2f us @2.4GHz... clock is 100MHz-based if small)" % (B, N, 1e3*ms/N, tot/N, tot/N/2400))

@@ -4,6 +4,10 @@
 //                     (the MFMA fragment packing, the K permutation, the gated tile pairing, the prefetch ring)
 //   wnp_softmax_pick  wn::softmax_pick (max / sum / scan / inverse-CDF pick over LPU lanes per utterance)
 //   wnp_handoff       wn::send_tiles / recv_tiles_fast between two workgroups (tagged granules, both store scopes)
+//   wnp_stream_walk   pack_layer_kernel + Cfg::streamPos -> the per-wave weight stream walked exactly like wavenet_wg walks
+//                     it (buffer-resource ring: gemm_b / take_group / refill_group / skip_frags, the wrap behind the head)
+//   wnp_gate          the fp16 engine's gate on pre-scaled pre-activations (gate1<true> and the staged gate_stage)
+//   wnp_hog_*         a kernel that holds a number of CUs for a while (the chain's fault-tolerance test)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void handoff_kernel(unsigned long long* mail, 
     unsigned long long* box = mail + 64 * ((gridDim.x + 63) / 64) + (size_t)pair * (MSG + ACK);
     gu32* st = (gu32*)status;
     bool same = false;
-    if (!chain_place(place, blockIdx.x, blockIdx.x ^ 1, st, same)) return;
+    if (!chain_place(place, blockIdx.x, blockIdx.x ^ 1, st, same, kChainTimeoutTicks)) return;
     if (role == 0 && threadIdx.x == 0) sameOut[pair] = same ? 1 : 0;
     if (forceAgent) same = false;
     unsigned long long acc = 0;
@@ -151,10 +155,10 @@ __global__ __launch_bounds__(256) void handoff_kernel(unsigned long long* mail, 
             send_tiles<NT, NW>(box, w, lane, tag, v, same);
             // wait for the consumer's acknowledgement of this round before overwriting the single slot
             floatx4 ack[1];
-            if (!recv_tiles<1, NW>(box + MSG, w, lane, tag, ack, st, 0x700u)) return;
+            if (!recv_tiles<1, NW>(box + MSG, w, lane, tag, ack, st, 0x700u, kChainTimeoutTicks)) return;
         } else {
             floatx4 v[NT];
-            if (!recv_tiles_fast<NT, NW>(box, w, lane, tag, v, st, 0x600u)) return;
+            if (!recv_tiles_fast<NT, NW>(box, w, lane, tag, v, st, 0x600u, kChainTimeoutTicks)) return;
 #pragma unroll
             for (int i = 0; i < NT; i++)
 #pragma unroll
@@ -168,6 +172,182 @@ __global__ __launch_bounds__(256) void handoff_kernel(unsigned long long* mail, 
     }
     if (role == 1) atomicAdd(&sums[pair], acc);
 }
+
+// ---- the weight stream of a whole model walked the way wavenet_wg walks it ---------------------------------------------
+// One workgroup, one tile of 16 columns X.  Every wave goes through its stream in consumption order
+//   cur(0) res(0) prev(1) | cur(1) skip(0) res(1) prev(2) | ... | cur(L-1) skip(L-2) res(L-1) prev(0) | skip(L-1) | zs pad za pad
+// with the buffer-resource prefetch ring (take_group / refill_group inside gemm_b, skip_frags over the padding), `passes`
+// times (the ring wraps behind the head onto layer 0), and writes W X of every matrix: out[pass][l] = prev 2R | cur 2R |
+// res R | skip S rows of 16, then zs A | za A.  (prev(0) of a pass is the one taken at the end of that pass.)
+template <bool F16, int R, int S, int A>
+__global__ __launch_bounds__((Cfg<F16, R, S, A, 3>::THREADS)) void stream_walk_kernel(const void* wblob, const float* X, float* out, int L, int passes) {
+    using C = Cfg<F16, R, S, A, 3>;            // (three tiles per workgroup: the configuration that streams the WHOLE head)
+    using P = Prec<F16>;
+    using frag = typename P::frag;
+    constexpr int PF = C::PF, FLW = C::FLW, NW = C::NW, HTW = C::HTW, STW = C::STW, ATW = C::ATW, RT = C::RT;
+    constexpr int KF_R = C::KF_R, KF_S = C::KF_S, KF_A = C::KF_A;
+    static_assert(C::HS == C::FHW, "this walk expects the whole head in the stream");
+    __shared__ __attribute__((aligned(16))) char xr[KF_R * 1024], xs[KF_S * 1024], xa[KF_A * 1024];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    auto put = [&](char* buf, int tiles) {
+        for (int t = w; t < tiles; t += NW) {
+            floatx4 v;
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = X[(t * 16 + g * 4 + r) * 16 + j];
+            lds_put_tile<F16>(buf, t, lane, v);
+        }
+    };
+    put(xr, R / 16), put(xs, S / 16), put(xa, A / 16);
+    __syncthreads();
+    frag br[1][KF_R], bs[1][KF_S], ba[1][KF_A];
+    lds_get_frags<F16, KF_R>(xr, lane, br[0]);
+    lds_get_frags<F16, KF_S>(xs, lane, bs[0]);
+    lds_get_frags<F16, KF_A>(xa, lane, ba[0]);
+    const unsigned laneOff = lane * 16u;
+    const char* wbase = (const char*)wblob + (size_t)w * C::waveStreamFrags(L) * 1024;
+    const rsrc_t rs = make_rsrc(wbase);
+    WStream<F16, PF, F16> ws;
+#pragma unroll
+    for (int i = 0; i < PF; i++) ws.buf[i] = buf_load<frag>(rs, laneOff + (unsigned)(i & 3) * 1024u, (unsigned)(i & ~3) * 1024u);
+    const size_t perLayer = (size_t)(5 * R + S) * 16, perPass = (size_t)L * perLayer + (size_t)2 * A * 16;
+    auto zero = [](auto& acc) {
+        for (auto& t : acc[0]) t = floatx4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto storeGate = [&](float* dst, const floatx4 (&acc)[1][2 * HTW]) {     // gated pairs: slot 2i = tile w + NW i, slot 2i+1 = + RT
+#pragma unroll
+        for (int i = 0; i < 2 * HTW; i++) {
+            const int tile = w + NW * (i >> 1) + (i & 1) * RT;
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(tile * 16 + g * 4 + r) * 16 + j] = acc[0][i][r];
+        }
+    };
+    auto storePlain = [&](float* dst, const auto& acc, int n) {
+        for (int i = 0; i < n; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[((w + NW * i) * 16 + g * 4 + r) * 16 + j] = acc[0][i][r];
+    };
+    for (int pass = 0; pass < passes; pass++) {
+        float* po = out + (size_t)pass * perPass;
+        for (int l = 0; l < L; l++) {
+            const int wl = (l - 1) * FLW;
+            floatx4 cur[1][2 * HTW], res[1][HTW], prv[1][2 * HTW];
+            zero(cur), zero(res), zero(prv);
+            gemm_b<F16, PF, 0, 1, 2 * HTW, KF_R>(ws, rs, l ? C::P_CUR : C::P_CUR0, wl, 0, laneOff, cur, br);
+            storeGate(po + l * perLayer + 2 * R * 16, cur);
+            if (l) {
+                floatx4 sk[1][STW];
+                zero(sk);
+                gemm_b<F16, PF, 0, 1, STW, KF_R>(ws, rs, C::P_SKIP, wl, 0, laneOff, sk, br);
+                storePlain(po + (l - 1) * perLayer + 5 * R * 16, sk, STW);
+            }
+            gemm_b<F16, PF, 0, 1, HTW, KF_R>(ws, rs, C::P_RES, wl, 0, laneOff, res, br);
+            storePlain(po + l * perLayer + 4 * R * 16, res, HTW);
+            gemm_b<F16, PF, 0, 1, 2 * HTW, KF_R>(ws, rs, C::P_PREV, wl, 0, laneOff, prv, br);
+            storeGate(po + (l + 1 < L ? l + 1 : 0) * perLayer, prv);
+        }
+        {
+            floatx4 sk[1][STW];
+            zero(sk);
+            gemm_b<F16, PF, 0, 1, STW, KF_R>(ws, rs, C::P_CUR, (L - 1) * FLW, 0, laneOff, sk, br);
+            storePlain(po + (L - 1) * perLayer + 5 * R * 16, sk, STW);
+        }
+        floatx4 zs[1][ATW], za[1][ATW];
+        zero(zs), zero(za);
+        gemm_b<F16, PF, C::HSP, 1, ATW, KF_S>(ws, rs, C::O_ZS, L * FLW, 0, laneOff, zs, bs);
+        skip_frags<F16, PF, C::HSP, F16, C::PAD1>(ws, rs, C::FW_ZS, L * FLW, 0, laneOff);
+        gemm_b<F16, PF, C::HSP, 1, ATW, KF_A>(ws, rs, C::O_ZA, L * FLW, 0, laneOff, za, ba);
+        skip_frags<F16, PF, C::HSP, F16, C::PAD2>(ws, rs, C::O_ZA + C::FW_ZA, L * FLW, 0, laneOff);
+        storePlain(po + L * perLayer, zs, ATW);
+        storePlain(po + L * perLayer + A * 16, za, ATW);
+    }
+}
+
+// W: per layer [Wprev 2RxR | Wcur 2RxR | Wres RxR | Wskip SxR] col-major, then Wzs AxS, Wza AxA; biases are not under test
+template <bool F16, int R, int S, int A>
+static int run_stream_walk(int L, int passes, const float* W, const float* X, float* out) {
+    using C = Cfg<F16, R, S, A, 3>;
+    using elem = typename Prec<F16>::elem;
+    const size_t perLayerW = (size_t)5 * R * R + (size_t)S * R, nW = L * perLayerW + (size_t)A * S + (size_t)A * A;
+    const size_t perPass = (size_t)L * (5 * R + S) * 16 + (size_t)2 * A * 16;
+    const int maxK = R > S ? (R > A ? R : A) : (S > A ? S : A);
+    float *dW, *dX, *dOut, *dBias;
+    elem* blob;
+    const size_t blobElems = (size_t)C::NW * C::waveStreamFrags(L) * C::FRAG_ELEMS;
+    CK(hipMalloc(&dW, sizeof(float) * nW));
+    CK(hipMalloc(&dX, sizeof(float) * maxK * 16));
+    CK(hipMalloc(&dOut, sizeof(float) * perPass * passes));
+    CK(hipMalloc(&dBias, sizeof(float) * (size_t)L * C::BIAS_L));
+    CK(hipMalloc(&blob, sizeof(elem) * blobElems));
+    CK(hipMemset(blob, 0, sizeof(elem) * blobElems));
+    CK(hipMemset(dBias, 0, sizeof(float) * (size_t)L * C::BIAS_L));
+    CK(hipMemset(dOut, 0xff, sizeof(float) * perPass * passes));
+    CK(hipMemcpy(dW, W, sizeof(float) * nW, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dX, X, sizeof(float) * maxK * 16, hipMemcpyHostToDevice));
+    for (int l = 0; l < L; l++) {           // exactly nvWavenetInfer::setLayerWeights
+        LayerSrc src;
+        const float* wl = dW + l * perLayerW;
+        src.Wprev = wl, src.Wcur = wl + 2 * R * R, src.Wres = wl + 4 * R * R, src.Wskip = wl + 5 * R * R;
+        src.Bh = dBias, src.Bres = dBias, src.Bskip = dBias;
+        hipLaunchKernelGGL((pack_layer_kernel<F16>), dim3(64), dim3(256), 0, 0, blob, dBias + (size_t)l * C::BIAS_L, src, R, S, C::NW,
+                           C::waveStreamFrags(L) * C::FRAG_ELEMS, (int)C::streamPos(l, C::O_PREV, L), (int)C::streamPos(l, C::O_CUR, L),
+                           (int)C::streamPos(l, C::O_RES, L), (int)C::streamPos(l, C::O_SKIP, L));
+    }
+    const size_t hf = C::headOffsetFrags(L);   // ... and setOutWeights
+    hipLaunchKernelGGL((pack_weight_kernel<F16>), dim3(64), dim3(256), 0, 0, blob + (hf + C::O_ZS) * C::FRAG_ELEMS, dW + L * perLayerW, A, S, C::NW,
+                       C::waveStreamFrags(L) * C::FRAG_ELEMS, 0);
+    hipLaunchKernelGGL((pack_weight_kernel<F16>), dim3(64), dim3(256), 0, 0, blob + (hf + C::O_ZA) * C::FRAG_ELEMS,
+                       dW + L * perLayerW + (size_t)A * S, A, A, C::NW, C::waveStreamFrags(L) * C::FRAG_ELEMS, 0);
+    hipLaunchKernelGGL((stream_walk_kernel<F16, R, S, A>), dim3(1), dim3(C::THREADS), 0, 0, (const void*)blob, dX, dOut, L, passes);
+    CK(hipGetLastError());
+    CK(hipMemcpy(out, dOut, sizeof(float) * perPass * passes, hipMemcpyDeviceToHost));
+    CK(hipFree(dW));
+    CK(hipFree(dX));
+    CK(hipFree(dOut));
+    CK(hipFree(dBias));
+    CK(hipFree(blob));
+    return 0;
+}
+
+// h = tanh(a) sigmoid(b) of the fp16 engine: pre-activations arrive pre-scaled (2 log2 e, -log2 e); way 0 = gate1<true>, way 1 =
+// the five-stage form wavenet_wg interleaves with MFMAs
+__global__ void gate_kernel(const float* a, const float* b, float* h, int n, int way) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * i + 1 >= n) return;
+    const float a0 = a[2 * i] * gate_prescale<true>(false), a1 = a[2 * i + 1] * gate_prescale<true>(false);
+    const float b0 = b[2 * i] * gate_prescale<true>(true), b1 = b[2 * i + 1] * gate_prescale<true>(true);
+    if (way == 0) {
+        h[2 * i] = gate1<true>(a0, b0);
+        h[2 * i + 1] = gate1<true>(a1, b1);
+    } else {
+        floatx2 ea, eb, ra, rb, hp;
+        gate_stage<true, 0>(a0, a1, b0, b1, ea, eb, ra, rb, hp);
+        gate_stage<true, 1>(a0, a1, b0, b1, ea, eb, ra, rb, hp);
+        gate_stage<true, 2>(a0, a1, b0, b1, ea, eb, ra, rb, hp);
+        gate_stage<true, 3>(a0, a1, b0, b1, ea, eb, ra, rb, hp);
+        gate_stage<true, 4>(a0, a1, b0, b1, ea, eb, ra, rb, hp);
+        h[2 * i] = hp[0];
+        h[2 * i + 1] = hp[1];
+    }
+}
+
+// holds `blockIdx` CUs (100 KiB of LDS per workgroup: one per CU, and nothing with a large LDS footprint fits beside it)
+// until the wall clock passes `until`
+__global__ __launch_bounds__(64) void hog_kernel(long long ticks, unsigned* sink) {
+    extern __shared__ char hogLds[];
+    const long long t0 = (long long)wall_clock64();
+    unsigned n = 0;
+    while ((long long)wall_clock64() - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        n++;
+    }
+    if (threadIdx.x == 0) {
+        hogLds[0] = (char)n;
+        sink[blockIdx.x] = n + (unsigned)hogLds[0];
+    }
+}
+static hipStream_t g_hogStream = nullptr;
+static unsigned* g_hogSink = nullptr;
 
 extern "C" {
 
@@ -189,6 +369,50 @@ int wnp_gemm(int precision, int M, int K, int nw, int gated, const float* W, con
     BOTH(128, 32, 2, false)
     BOTH(512, 256, 4, false)   // A = 512
     return -2;
+}
+
+// the whole weight stream of an L-layer model; see stream_walk_kernel for the layouts
+int wnp_stream_walk(int precision, int R, int S, int A, int L, int passes, const float* W, const float* X, float* out) {
+#define WALK(F16, r, s, a) \
+    if ((precision == 16) == F16 && R == r && S == s && A == a) return run_stream_walk<F16, r, s, a>(L, passes, W, X, out);
+    WALK(true, 64, 256, 256)
+    WALK(false, 64, 256, 256)
+    WALK(true, 64, 128, 256)
+    WALK(true, 128, 256, 256)
+    WALK(false, 32, 128, 256)
+    return -2;
+}
+
+int wnp_gate(int n, int way, const float* a, const float* b, float* h) {
+    float *da, *db, *dh;
+    CK(hipMalloc(&da, sizeof(float) * n));
+    CK(hipMalloc(&db, sizeof(float) * n));
+    CK(hipMalloc(&dh, sizeof(float) * n));
+    CK(hipMemcpy(da, a, sizeof(float) * n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, b, sizeof(float) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gate_kernel, dim3((n / 2 + 255) / 256), dim3(256), 0, 0, da, db, dh, n, way);
+    CK(hipGetLastError());
+    CK(hipMemcpy(h, dh, sizeof(float) * n, hipMemcpyDeviceToHost));
+    CK(hipFree(da));
+    CK(hipFree(db));
+    CK(hipFree(dh));
+    return 0;
+}
+
+// asynchronously: `cus` workgroups of one wave and 100 KiB of LDS each spin for `ms` milliseconds on a stream of their own
+int wnp_hog_start(int cus, double ms) {
+    if (!g_hogStream) {
+        CK(hipStreamCreateWithFlags(&g_hogStream, hipStreamNonBlocking));
+        CK(hipMalloc(&g_hogSink, 4096 * sizeof(unsigned)));
+        CK(hipFuncSetAttribute((const void*)hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    }
+    hipLaunchKernelGGL(hog_kernel, dim3(cus), dim3(64), 100 * 1024, g_hogStream, (long long)(ms * 1e5), g_hogSink);
+    CK(hipGetLastError());
+    return 0;
+}
+int wnp_hog_wait(void) {
+    if (g_hogStream) CK(hipStreamSynchronize(g_hogStream));
+    return 0;
 }
 
 int wnp_softmax_pick(int A, int nw, const float* logits, const float* sel, int* picks, float* probs) {

@@ -26,6 +26,8 @@ def prim():
     lib.wnp_softmax_pick.argtypes = [C.c_int, C.c_int, _fp, _fp, C.POINTER(C.c_int), _fp]
     lib.wnp_handoff.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                 C.POINTER(C.c_int), C.POINTER(C.c_uint)]
+    lib.wnp_stream_walk.argtypes = [C.c_int] * 6 + [_fp, _fp, _fp]
+    lib.wnp_gate.argtypes = [C.c_int, C.c_int, _fp, _fp, _fp]
     return lib
 
 
@@ -140,3 +142,85 @@ def test_handoff_granules_under_uneven_load(prim, force_agent):
     assert all(b == 0 for b in bad), "corrupted words per pair: %s" % [int(b) for b in bad if b][:5]
     assert all(g == words for g in good), (int(good[0]), words)
     print("pairs on one XCD: %d of %d" % (sum(same), pairs))
+
+
+@pytest.mark.parametrize("precision,R,S,A,L", [(16, 64, 256, 256, 5), (32, 64, 256, 256, 3), (16, 64, 128, 256, 4), (16, 128, 256, 256, 3),
+                                               (32, 32, 128, 256, 4), (16, 64, 256, 256, 2)])
+def test_weight_stream_walk_is_exact_on_small_integers(prim, precision, R, S, A, L):
+    """What wavenet_wg actually runs since round 2: pack_layer_kernel lays every layer's four matrices into the per-wave
+    streams at Cfg::streamPos (consumption order, the skip GEMM of a layer behind the next layer's current tap, the dilated
+    tap of layer l+1 at the end of layer l, prev(0) behind the last layer), the head follows padded to whole ring turns;
+    the kernel walks that stream through the buffer-resource prefetch ring (gemm_b / take_group / refill_group /
+    skip_frags) for TWO samples, so the wrap from the head back to layer 0 is exercised.  Small-integer matrices: every
+    W X must come out exact (fp16 gated matrices: at the packed pre-scale, like the GEMM test above), both passes."""
+    rng = np.random.default_rng(precision * 7 + R + S + A + L)
+    K = max(R, S, A)
+    X = rng.integers(-1, 2, size=(K, 16)).astype(np.float32)
+    X[:, 0] = 1
+    mats, Wflat = [], []
+    for l in range(L):
+        per = []
+        for (M, KK) in ((2 * R, R), (2 * R, R), (R, R), (S, R)):
+            W = rng.integers(-2, 3, size=(M, KK)).astype(np.float32)
+            W[0, :] = 1 + (np.arange(KK) + l) % 2
+            per.append(W)
+            Wflat.append(np.ascontiguousarray(W.T).ravel())      # col-major
+        mats.append(per)
+    Wzs = rng.integers(-2, 3, size=(A, S)).astype(np.float32)
+    Wza = rng.integers(-2, 3, size=(A, A)).astype(np.float32)
+    Wflat += [np.ascontiguousarray(Wzs.T).ravel(), np.ascontiguousarray(Wza.T).ravel()]
+    Wflat = np.concatenate(Wflat).astype(np.float32)
+    per_pass = L * (5 * R + S) * 16 + 2 * A * 16
+    passes = 2
+    out = np.full(per_pass * passes, np.nan, dtype=np.float32)
+    assert prim.wnp_stream_walk(precision, R, S, A, L, passes, _f(Wflat), _f(X), _f(out)) == 0
+    scale = np.where(np.arange(2 * R) < R, 2.88539008177792681472, -1.44269504088896340736)
+
+    def want(W, gated, KK):
+        Wd = W.astype(np.float64)
+        if gated and precision == 16:
+            Wd = (W * scale[:, None]).astype(np.float16).astype(np.float64)
+        return Wd @ X[:KK].astype(np.float64)
+    for ps in range(passes):
+        o = out[ps * per_pass:(ps + 1) * per_pass]
+        at = 0
+        for l in range(L):
+            for name, W, gated in (("prev", mats[l][0], True), ("cur", mats[l][1], True), ("res", mats[l][2], False), ("skip", mats[l][3], False)):
+                M = W.shape[0]
+                got = o[at:at + M * 16].reshape(M, 16)
+                at += M * 16
+                ref = want(W, gated, R)
+                if gated and precision == 16:
+                    assert np.allclose(got, ref, rtol=1e-6, atol=1e-4), (ps, l, name, np.abs(got - ref).max())
+                else:
+                    assert np.array_equal(got, ref.astype(np.float32)), (ps, l, name, np.argwhere(got != ref)[:3].tolist())
+        for name, W, KK in (("zs", Wzs, S), ("za", Wza, A)):
+            got = o[at:at + A * 16].reshape(A, 16)
+            at += A * 16
+            assert np.array_equal(got, want(W, False, KK).astype(np.float32)), (ps, name)
+
+
+@pytest.mark.parametrize("way", [0, 1])
+def test_fp16_gate_on_prescaled_inputs(prim, way):
+    """The fp16 engine's gate (nv_wavenet_util.cuh:78-86 is what it replaces: tanhf * sigmoid in fp32): pre-activations arrive
+    pre-scaled by 2 log2 e / -log2 e and the gate is exp2 / rcp only,  tanh a = 1 - 2 / (2^a' + 1),  sigmoid b = 1 / (1 + 2^b').
+    v_exp_f32 and v_rcp_f32 are good to 1 ulp, so both factors carry an ABSOLUTE error of a few 1e-7 (the tanh form
+    cancels for small |a|: its relative error there is large, its absolute error is not) -- three orders of magnitude
+    below the fp16 rounding h gets next (u = 4.9e-4).  Stated bound: |h - tanh(a) sigmoid(b)| <= 1e-6 on [-8, 8]^2 plus the
+    saturated corners, for the one-shot form (way 0) and the five-stage form wavenet_wg interleaves with MFMAs (way 1),
+    which must agree with each other bit for bit."""
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    a = rng.uniform(-8, 8, n).astype(np.float32)
+    b = rng.uniform(-8, 8, n).astype(np.float32)
+    a[:8] = [0, 1e-4, -1e-4, 30, -30, 0.5, -0.5, 88]
+    b[:8] = [0, 30, -30, 0, 0, 88, -88, 0.25]
+    h = np.full(n, np.nan, dtype=np.float32)
+    assert prim.wnp_gate(n, way, _f(a), _f(b), _f(h)) == 0
+    ref = np.tanh(a.astype(np.float64)) / (1 + np.exp(-b.astype(np.float64)))
+    err = np.abs(h - ref)
+    assert np.all(np.isfinite(h)) and err.max() <= 1e-6, (err.max(), a[err.argmax()], b[err.argmax()])
+    h0 = np.full(n, np.nan, dtype=np.float32)
+    assert prim.wnp_gate(n, 0, _f(a), _f(b), _f(h0)) == 0
+    assert np.array_equal(h, h0)
+    print("fp16-engine gate, way %d: max |error| %.3g over %d points" % (way, err.max(), n))
