@@ -230,10 +230,12 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, 3>::THREADS)) void stream_walk_k
     for (int pass = 0; pass < passes; pass++) {
         float* po = out + (size_t)pass * perPass;
         for (int l = 0; l < L; l++) {
-            const int wl = (l - 1) * FLW;
+            // (exactly wavenet_wg's position arithmetic: layer 0 counts from the start of the stream)
+            const int wl = l ? (l - 1) * FLW : 0;
             floatx4 cur[1][2 * HTW], res[1][HTW], prv[1][2 * HTW];
             zero(cur), zero(res), zero(prv);
-            gemm_b<F16, PF, 0, 1, 2 * HTW, KF_R>(ws, rs, l ? C::P_CUR : C::P_CUR0, wl, 0, laneOff, cur, br);
+            if (l) gemm_b<F16, PF, 0, 1, 2 * HTW, KF_R>(ws, rs, C::P_CUR, wl, 0, laneOff, cur, br);
+            else gemm_b<F16, PF, 0, 1, 2 * HTW, KF_R>(ws, rs, C::P_CUR0 - FLW, wl, 0, laneOff, cur, br);
             storeGate(po + l * perLayer + 2 * R * 16, cur);
             if (l) {
                 floatx4 sk[1][STW];
@@ -241,9 +243,14 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, 3>::THREADS)) void stream_walk_k
                 gemm_b<F16, PF, 0, 1, STW, KF_R>(ws, rs, C::P_SKIP, wl, 0, laneOff, sk, br);
                 storePlain(po + (l - 1) * perLayer + 5 * R * 16, sk, STW);
             }
-            gemm_b<F16, PF, 0, 1, HTW, KF_R>(ws, rs, C::P_RES, wl, 0, laneOff, res, br);
+            if (l) {
+                gemm_b<F16, PF, 0, 1, HTW, KF_R>(ws, rs, C::P_RES, wl, 0, laneOff, res, br);
+                gemm_b<F16, PF, 0, 1, 2 * HTW, KF_R>(ws, rs, C::P_PREV, wl, 0, laneOff, prv, br);
+            } else {
+                gemm_b<F16, PF, 0, 1, HTW, KF_R>(ws, rs, C::P_RES - FLW, wl, 0, laneOff, res, br);
+                gemm_b<F16, PF, 0, 1, 2 * HTW, KF_R>(ws, rs, C::P_PREV - FLW, wl, 0, laneOff, prv, br);
+            }
             storePlain(po + l * perLayer + 4 * R * 16, res, HTW);
-            gemm_b<F16, PF, 0, 1, 2 * HTW, KF_R>(ws, rs, C::P_PREV, wl, 0, laneOff, prv, br);
             storeGate(po + (l + 1 < L ? l + 1 : 0) * perLayer, prv);
         }
         {
@@ -380,6 +387,7 @@ int wnp_stream_walk(int precision, int R, int S, int A, int L, int passes, const
     WALK(true, 64, 128, 256)
     WALK(true, 128, 256, 256)
     WALK(false, 32, 128, 256)
+    WALK(true, 32, 256, 256)       // FLW = 13 fragments per layer and wave: only a ring of depth 1 divides it
     return -2;
 }
 

@@ -145,7 +145,7 @@ def test_handoff_granules_under_uneven_load(prim, force_agent):
 
 
 @pytest.mark.parametrize("precision,R,S,A,L", [(16, 64, 256, 256, 5), (32, 64, 256, 256, 3), (16, 64, 128, 256, 4), (16, 128, 256, 256, 3),
-                                               (32, 32, 128, 256, 4), (16, 64, 256, 256, 2)])
+                                               (32, 32, 128, 256, 4), (16, 64, 256, 256, 2), (16, 32, 256, 256, 3)])
 def test_weight_stream_walk_is_exact_on_small_integers(prim, precision, R, S, A, L):
     """What wavenet_wg actually runs since round 2: pack_layer_kernel lays every layer's four matrices into the per-wave
     streams at Cfg::streamPos (consumption order, the skip GEMM of a layer behind the next layer's current tap, the dilated

@@ -63,7 +63,7 @@ def engine_getters(e, L):
                 Zs=e.getZs(), Za=e.getZa(), P=e.getP())
 
 
-def matrix_compare(name, ref, got, tol, relu=False):
+def matrix_compare(name, ref, got, tol, relu=False, atol_eps=4):
     """The reference's matrix_compare (matrix.cpp:133-151) with two repairs.  It passes when
     |got/ref| - 1 <= tol: (1) that is one-sided and lets a too-small magnitude through, here
     |got - ref| <= tol*|ref| both ways; (2) a purely relative bar is meaningless for elements that
@@ -75,7 +75,7 @@ def matrix_compare(name, ref, got, tol, relu=False):
     got = np.asarray(got, dtype=np.float64)
     assert ref.shape == got.shape, (name, ref.shape, got.shape)
     assert np.all(np.isfinite(got)), name + ": non-finite values"
-    atol = 4 * 1.1920929e-07 * np.abs(ref).max()
+    atol = atol_eps * 1.1920929e-07 * np.abs(ref).max()
     ok = np.abs(got - ref) <= tol * np.abs(ref) + atol
     if relu:
         r = (ref <= 0) | (got <= 0)
@@ -86,10 +86,15 @@ def matrix_compare(name, ref, got, tol, relu=False):
                              (name, tuple(idx), ref[tuple(idx)], got[tuple(idx)], tol, atol, (~ok).sum(), ok.size))
 
 
-def compare_activations(ref, got, tols=None, names=("Xout", "skipOut", "Zs", "Za", "P")):
+def compare_activations(ref, got, tols=None, names=("Xout", "skipOut", "Zs", "Za", "P"), atol_eps=4):
+    """atol_eps: the absolute term in units of eps32 * max|tensor|.  4 for the reference's own recipe (every tensor is a
+    sum of same-sized terms); on the O(1) recipe a K = 256 dot product of order-one terms that cancels to 1e-3 carries a
+    summation-order error of ~sqrt(K) eps * rms|term| ~ 16 eps * 0.3 (4 sigma over 1e4 elements: ~20 eps * max), which no
+    fp32 implementation with another summation order can avoid: 32 there.  (A broken network moves these tensors by
+    1e5 such units: tests/test_parity_bars_cpu.py.)"""
     tols = tols or cases.TOL
     for k in names:
-        matrix_compare(k, ref[k], got[k], tols[k], cases.RELU_AWARE[k])
+        matrix_compare(k, ref[k], got[k], tols[k], cases.RELU_AWARE[k], atol_eps)
 
 
 def explain_mismatches(y_ref, y_got, lo, hi, sel_bn, eps):
