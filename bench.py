@@ -623,15 +623,17 @@ def main():
             assert kname == HEADLINE_KERNELS[bt], kinfo     # the launches the parity tests pin
         # workgroups (weight-stream passes) per sample
         passes = (tiles + bt - 1) // bt
-        traffic = None
-        # HBM bytes per launch from the PMC passes of the latest profiled round (profiles/traffic_rNN.json,
-        # written by scripts/make_profiles.sh); only valid for the launch shape it was measured on
+        traffic, lds_counter, traffic_file = None, None, None
+        # HBM and LDS bytes per launch from the PMC passes of the latest profiled round (profiles/traffic_rNN.json, written
+        # by scripts/make_profiles_r3.py from rocprofv3 counters); only valid for the launch shape it was measured on
         import glob
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
             try:
                 tj = json.load(open(tf))
                 if tj.get("batch") == B and tj.get("samples") == N:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    lds_counter = tj.get("lds_bytes_per_launch")
+                    traffic_file = os.path.relpath(tf, ROOT)
                     break
             except Exception:
                 pass
@@ -645,9 +647,12 @@ def main():
             roofline["l2_weight_stream"] = dict(achieved=passes * N * HEAD.weight_bytes / (kern_ms * 1e-3) / 1e9,
                                                 peak=L2_PEAK_GBS, unit="GB/s")
             roofline["l2_weight_stream"]["frac"] = roofline["l2_weight_stream"]["achieved"] / L2_PEAK_GBS
-            roofline["lds"] = dict(achieved=passes * N * lds_bytes_per_sample(bt) / (kern_ms * 1e-3) / 1e9,
-                                   peak=LDS_PEAK_GBS, unit="GB/s", source="algorithmic bytes (exchange images, bias quads, logits); "
-                                   "counter-based figure: profiles/r03_pmc_lds_*.txt")
+            lds_alg = passes * N * lds_bytes_per_sample(bt)
+            # rocprof-reported when this launch shape was profiled: (SQ_INSTS_LDS_LOAD_BANDWIDTH + SQ_INSTS_LDS_STORE_BANDWIDTH) x 64 B
+            roofline["lds"] = dict(achieved=(lds_counter or lds_alg) / (kern_ms * 1e-3) / 1e9, peak=LDS_PEAK_GBS, unit="GB/s",
+                                   bytes_per_launch=lds_counter or lds_alg, algorithmic_bytes_per_launch=lds_alg,
+                                   source=("rocprofv3 counters of this launch shape (%s, profiles/r03_pmc_wg_b12288.txt)" % traffic_file)
+                                   if lds_counter else "algorithmic bytes (exchange images, bias quads, logits): this launch shape was not profiled")
             roofline["lds"]["frac"] = roofline["lds"]["achieved"] / LDS_PEAK_GBS
         out = {
             "metric": "samples/sec (all GPUs) at the max real-time batch @24kHz, R64/S256/A256 20L fp16",

@@ -754,6 +754,19 @@ public:
         p.useRng = m_useRng ? 1 : 0;
         p.rngKey0 = (unsigned)m_rngSeed;
         p.rngKey1 = (unsigned)(m_rngSeed >> 32);
+        {
+            // dilation schedule (nv_wavenet.cuh:99,110-111) as a table in the kernel arguments: dilation and first ring slot
+            int d = 1, off = 0;
+            for (int l = 0; l < m_numLayers; l++) {
+                p.dil[l].d = d;
+                p.dil[l].off = off;
+                off += d;
+                d <<= 1;
+                if (d > m_maxDilation) d = 1;
+            }
+            p.dil[m_numLayers] = p.dil[0];
+            p.dil[m_numLayers + 1] = p.dil[1];
+        }
         m_lastStride = num_samples;
         if (p.count <= 0) return true;
 

@@ -86,6 +86,8 @@ template <> struct Prec<false> {
     static constexpr int TPF = 1;
 };
 
+constexpr int kMaxLayers = 128;
+
 constexpr int pick_pf(int fl, int pfmax) {
     int best = 1;
     for (int d = 1; d <= pfmax && d <= fl; d++)
@@ -214,10 +216,10 @@ struct Cfg {
     __host__ __device__ static size_t waveStreamFrags(int L) { return (size_t)L * FLW + FHWP; }
 };
 
-constexpr int kMaxLayers = 128;
-
-// Dilation d_l and first ring slot of layer l, advanced layer by layer with scalar arithmetic
-// (no table loads: a load result needed "now" would wait behind the in-flight weight prefetch).
+// Dilation d_l and first ring slot of layer l.  wavenet_wg reads them from a table that travels in the kernel arguments
+// (Params::dil, filled by the host): indexing the argument segment with a uniform layer number is a scalar load -- it does
+// not queue behind the weight prefetch like a vector load would -- and replaces ~15 scalar ALU instructions per layer of
+// schedule arithmetic (round 3).  The chain computes its few entries once per launch with dil_next.
 struct Dil {
     int d, off;
 };
@@ -269,6 +271,7 @@ struct Params {
     int embLds;              // embedding tables held in LDS: 0 none, 1 current tap, 2 both
     int useRng;              // selectors drawn in-kernel (Philox4x32-10) instead of read from `sel`
     unsigned rngKey0, rngKey1;
+    Dil dil[kMaxLayers + 2]; // schedule of layer l; entries L and L+1 repeat layers 0 and 1 (of the next sample)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -578,6 +581,9 @@ __host__ __device__ constexpr int take_g(int g, int pf) {     // group size: div
 }
 WN_DEV rsrc_t make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, -1, 0x00020000); }
 // AUX: cache policy bits of the instruction (0 = default, 2 = non-temporal / streaming)
+#ifndef WN_W_AUX
+#define WN_W_AUX 0           // cache policy of the weight stream (experiments: 16 = sc1, L1 bypass; 2 = nt)
+#endif
 template <typename FRAG, int AUX = 0> WN_DEV FRAG buf_load(rsrc_t rs, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(FRAG, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX));
 }
@@ -601,7 +607,7 @@ WN_DEV void refill_group(WStream<F16, PF, PIN>& ws, rsrc_t rs, int idx, int base
         const bool wr = WRAP > 0 && nidx >= WRAP;
         const int rel = wr ? nidx - WRAP : nidx;                         // compile-time after unrolling
         const int pos = (wr ? wrapPos : basePos) + (rel & ~3);           // uniform; never negative (see the layer-0 note in wavenet_wg)
-        ws.buf[(idx + i) % PF] = buf_load<frag>(rs, laneOff + (unsigned)(rel & 3) * 1024u, (unsigned)pos * 1024u);
+        ws.buf[(idx + i) % PF] = buf_load<frag, WN_W_AUX>(rs, laneOff + (unsigned)(rel & 3) * 1024u, (unsigned)pos * 1024u);
     }
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -749,10 +755,15 @@ WN_DEV int softmax_pick(const float* lrow, int sq, int lane, float sel, float (&
     for (int i = 1; i < RPL; i++) m = __builtin_fmaxf(m, e[i]);
     m = group_reduce_f<LPU>(m, [](float a, float b) { return __builtin_fmaxf(a, b); });
     float lsum = 0.f;
+    {
+        // exp(x - m) = 2^(x log2 e - m log2 e): one fma in front of the v_exp_f32 instead of a subtraction and a multiplication
+        constexpr float kLog2e = 1.44269504088896340736f;
+        const float mneg = -m * kLog2e;
 #pragma unroll
-    for (int i = 0; i < RPL; i++) {
-        e[i] = fast_exp(e[i] - m);
-        lsum += e[i];
+        for (int i = 0; i < RPL; i++) {
+            e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[i], kLog2e, mneg));
+            lsum += e[i];
+        }
     }
     // inclusive scan of the lane sums over the LPU lanes of this utterance (row_shr:o reads lane - o of the row)
     float incl = lsum;
@@ -774,12 +785,14 @@ WN_DEV int softmax_pick(const float* lrow, int sq, int lane, float sel, float (&
     total = group_reduce_f<LPU>(incl, [](float a, float b) { return __builtin_fmaxf(a, b); });
     const float target = sel * total;
     // first row of this lane whose cumulative sum exceeds the target
+    // The running sums of non-negative terms never decrease, so the rows whose sum does NOT exceed the target form a prefix:
+    // its length is the first row that does (compare + add-with-carry per row instead of two compares and a select).
     float cum = incl - lsum;   // exclusive prefix of this lane
-    int first = RPL;
+    int first = 0;
 #pragma unroll
     for (int i = 0; i < RPL; i++) {
         cum += e[i];
-        first = (first == RPL && target < cum) ? i : first;
+        first += (cum <= target) ? 1 : 0;
     }
     int pick = first < RPL ? sq * RPL + first : 0x7fffffff;
     pick = group_min_i<LPU>(pick);
@@ -936,7 +949,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     WStream<F16, PF, ws_pin> ws;
     const rsrc_t rsW = make_rsrc(wbase);      // the wave's weight stream as a buffer: fragment positions become SGPR offsets
 #pragma unroll
-    for (int i = 0; i < PF; i++) ws.buf[i] = buf_load<frag>(rsW, laneOff + (unsigned)(i & 3) * 1024u, (unsigned)(i & ~3) * 1024u);
+    for (int i = 0; i < PF; i++) ws.buf[i] = buf_load<frag, WN_W_AUX>(rsW, laneOff + (unsigned)(i & 3) * 1024u, (unsigned)(i & ~3) * 1024u);
 
     // ---- prefetch of the dilated input + conditioning of (sample tn, layer ln) ----------------
     // ---- resident head weights ------------------------------------------------------------------
@@ -1048,8 +1061,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #endif
         }
     };
-    prefetch(p.initSample, 0, dil_first(), xpA, cdA);
-    prefetch(p.initSample, 1, dil_next(dil_first(), p.maxDilation, false), xpB, cdB);
+    prefetch(p.initSample, 0, p.dil[0], xpA, cdA);
+    prefetch(p.initSample, 1, p.dil[1], xpB, cdB);
     // publish this wave's fragments of the NEXT layer's dilated tap to LDS
     // (before the start, t < d, the tap is zero -- reference :287: zeros are published then; two store sequences under
     // a uniform branch rather than selects on the fragments, the zero case is the first d samples only)
@@ -1135,14 +1148,16 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     for (int t = p.initSample; t < tEnd; t++) {
         const bool dumpNow = DUMP && p.dump && (t == tEnd - 1);
 
-        // selector of the utterance this lane serves in the softmax
+        // selector of the utterance this lane serves in the softmax: from the uploaded table (requested here, a whole sample
+        // before its use) or drawn in-kernel (further down, next to the head GEMMs)
         float selv[BT];
+        if (!p.useRng) {
 #pragma unroll
-        for (int bt = 0; bt < BT; bt++) {
-            int sb = (tile0 + bt) * 16 + su;
-            sb = sb < p.batch ? sb : p.batch - 1;
-            selv[bt] = p.useRng ? philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)sb)
-                                : p.sel[(size_t)t * p.maxBatch + sb];
+            for (int bt = 0; bt < BT; bt++) {
+                int sb = (tile0 + bt) * 16 + su;
+                sb = sb < p.batch ? sb : p.batch - 1;
+                selv[bt] = p.sel[(size_t)t * p.maxBatch + sb];
+            }
         }
 
         // ---- embedding (nv_wavenet_reference.cpp:42-56): each wave makes its own x tiles ------
@@ -1366,27 +1381,14 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             gemm_b<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, rsW, C::P_PREV - PB, wl, 0, laneOff, acc, xp);
         };
         {
-            // dK = schedule entry of layer (l+K) mod L  (l+1, l+2 may wrap into the next sample)
-            Dil d0 = dil_first();
-            Dil d1 = dil_next(d0, p.maxDilation, false);
-            Dil d2 = dil_next(d1, p.maxDilation, L == 2);
-            layer(std::false_type{}, 0, d0, d1, d2, xpA, cdA, xpB, cdB);
-            auto step = [&](const int l) {
-                d0 = d1;
-                d1 = d2;
-                d2 = dil_next(d1, p.maxDilation, l + 2 == L);   // layer index L is layer 0 of the next sample
-            };
+            // schedule entries of layers l, l+1, l+2 (the latter two may be layers 0, 1 of the next sample: table entries L, L+1)
+            layer(std::false_type{}, 0, p.dil[0], p.dil[1], p.dil[2], xpA, cdA, xpB, cdB);
             int l = 1;
             for (; l + 1 < L; l += 2) {
-                step(l);
-                layer(std::true_type{}, l, d0, d1, d2, xpB, cdB, xpA, cdA);
-                step(l + 1);
-                layer(std::true_type{}, l + 1, d0, d1, d2, xpA, cdA, xpB, cdB);
+                layer(std::true_type{}, l, p.dil[l], p.dil[l + 1], p.dil[l + 2], xpB, cdB, xpA, cdA);
+                layer(std::true_type{}, l + 1, p.dil[l + 1], p.dil[l + 2], p.dil[l + 3], xpA, cdA, xpB, cdB);
             }
-            if (l < L) {
-                step(l);
-                layer(std::true_type{}, l, d0, d1, d2, xpB, cdB, xpA, cdA);
-            }
+            if (l < L) layer(std::true_type{}, l, p.dil[l], p.dil[l + 1], p.dil[l + 2], xpB, cdB, xpA, cdA);
             if (L & 1) {
                 // odd layer count: layer 0 of the next sample was prefetched into the odd set
 #pragma unroll
@@ -1456,13 +1458,39 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int i = 0; i < ATW; i++)
                     za[bt][i] = *(const floatx4*)(headBias + A + (w + NW * i) * 16 + g * 4);
+            auto draw_selectors = [&]() {
+                // In-kernel selectors (Philox4x32-10, counter {sample, utterance}).  A wave instruction costs the same whether
+                // its lanes compute one value or sixteen different ones: with 16 softmax lanes per utterance (one DPP row),
+                // lane q < BT of every row draws the selector of tile q and the row takes it over with a row broadcast -- one
+                // Philox evaluation per sample instead of one per tile.  Placed here, its arithmetic fills the wait for the zs
+                // fragments instead of the head of the sample.
+                if (!p.useRng) return;
+                if constexpr (C::LPU == 16 && BT > 1) {
+                    const int q = sq < BT ? sq : 0;
+                    int sb = (tile0 + q) * 16 + su;
+                    sb = sb < p.batch ? sb : p.batch - 1;
+                    const float mine = philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)sb);
+                    selv[0] = dpp_f<0x150>(mine);                       // row_newbcast:0
+                    if constexpr (BT > 1) selv[1] = dpp_f<0x151>(mine);
+                    if constexpr (BT > 2) selv[2] = dpp_f<0x152>(mine);
+                } else {
+#pragma unroll
+                    for (int bt = 0; bt < BT; bt++) {
+                        int sb = (tile0 + bt) * 16 + su;
+                        sb = sb < p.batch ? sb : p.batch - 1;
+                        selv[bt] = philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)sb);
+                    }
+                }
+            };
             if constexpr (C::ZA_B_FROM_LDS) {
                 static_assert(HR == 0, "the LDS-streamed head is for the large, non-resident heads");
+                draw_selectors();
                 gemm_ldsb_b<F16, PF, C::HSP, BT, ATW, KF_A>(ws, rsW, C::O_ZA, L * FLW, 0, laneOff, za, zsbuf, lane);
             } else {
                 frag zb[BT][KF_A];
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_A>(zsbuf + bt * KF_A * 1024, lane, zb[bt]);
+                draw_selectors();
                 if constexpr (HR >= C::FW_ZA) gemm_res<F16, BT, ATW, KF_A>(hw, C::FW_ZS - HS, za, zb);
                 else gemm_b<F16, PF, C::HSP, BT, ATW, KF_A>(ws, rsW, C::O_ZA, L * FLW, 0, laneOff, za, zb);
             }

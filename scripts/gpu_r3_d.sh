@@ -1,0 +1,11 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+{
+echo "=== base"; timeout 600 python scripts/quick_abl.py w1,w3,g2,g3 2>&1 | tail -1
+for v in wsc1 wsc1pf18 pf18 wnt; do
+  echo "=== $v"; NVW_LIB=scripts/ubench/bld_$v/libwavenet_infer.so timeout 600 python scripts/quick_abl.py w1,w3,g2,g3 2>&1 | tail -1
+done
+echo "=== base again"; timeout 600 python scripts/quick_abl.py g2,g3 2>&1 | tail -1
+} > gpurun_out/r3d.log 2>&1
+cat gpurun_out/r3d.log
