@@ -49,8 +49,6 @@ nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int m
  *   1 wavenet_wg (1, 2 or 3 tiles of 16 utterances per workgroup by batch size)   2 / 3 / 4 wavenet_wg with exactly 1 / 2 / 3
  *   (three: fp16, R <= 64; two tiles otherwise)   5 wavenet_chain (multi-CU, resident weights, fewest CUs)
  *   6 wavenet_chain with one layer per CU.
- *   7 wavenet_split (eight waves per workgroup in two roles; fp16, R = 64, even layer counts -- anything else runs on wavenet_wg),
- *   1, 2 or 3 tiles per workgroup by batch size   8 / 9 / 10 wavenet_split with exactly 1 / 2 / 3.
  * Returns NULL when the shape does not fit a CU in that organisation (the reference's variants print
  * and return false for shapes they do not support, nv_wavenet_singleblock.cuh:273-286). */
 nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, int max_dilation,

@@ -18,7 +18,6 @@
 //                           through L2-visible tagged granules (wn_chain.hpp); fewest CUs that hold the model
 //   MANYBLOCK_NONPERSISTENT the same chain with one layer per CU
 //   AUTO                    chosen from (R, S, A, L, batch, CUs): see pickOrganisation()
-//   (organisation NVW_ORG_SPLIT) wn::wavenet_split: the single-workgroup organisation with two waves per SIMD in two roles
 // An explicit Organisation (last constructor argument, beyond the reference's signature) overrides.
 // batch_size_per_block is validated like the reference (nv_wavenet.cuh:559-561) but the batch tile is
 // fixed by the MFMA shape (16 utterances), so it is a no-op hint.  Device buffers are laid out for this
@@ -38,7 +37,6 @@
 
 #include "wn_chain.hpp"
 #include "wn_kernels.hpp"
-#include "wn_split_cfg.hpp"
 
 #ifndef gpuErrChk
 #define gpuErrChk(ans) { wnGpuAssert((ans), __FILE__, __LINE__); }
@@ -59,12 +57,7 @@ enum nvwOrganisation {
     NVW_ORG_WG3 = 4,      // wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64; else two)
     NVW_ORG_CHAIN = 5,    // wn::wavenet_chain, as many layers per CU as stay resident
     NVW_ORG_CHAIN1 = 6,   // wn::wavenet_chain, one layer per CU
-    NVW_ORG_SPLIT = 7,    // wn::wavenet_split: eight waves per workgroup in two roles (fp16, R = 64, even layer counts, production
-                          // launches; anything else runs on wn::wavenet_wg), one, two or three tiles per workgroup by batch size
-    NVW_ORG_SPLIT1 = 8,   // wn::wavenet_split, one tile per workgroup
-    NVW_ORG_SPLIT2 = 9,   // ... two
-    NVW_ORG_SPLIT3 = 10,  // ... three
-    NVW_ORG_LAST = NVW_ORG_SPLIT3
+    NVW_ORG_LAST = NVW_ORG_CHAIN1
 };
 
 template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
@@ -94,7 +87,6 @@ protected:
     int m_lastStride;    // row stride of m_yOut in the latest launch (= its num_samples)
 
     elem* m_wblob;      // packed weight fragments: L layers then the head
-    elem* m_wsplit;     // the same weights as wavenet_split's eight per-wave role streams (NULL when that kernel cannot run this model)
     float* m_bias;      // fp32 biases
     elem* m_embedPrev;  // [A][R]
     elem* m_embedCur;
@@ -165,63 +157,8 @@ protected:
         const float* d = onDevice(src, (size_t)M * K);
         hipLaunchKernelGGL((wn::pack_weight_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0,
                            m_wblob + blockFrag * C::FRAG_ELEMS, d, M, K, C::NW,
-                           C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS, gateRT, 0x7fffffff, (size_t)0);
+                           C::waveStreamFrags(m_numLayers) * C::FRAG_ELEMS, gateRT);
         gpuErrChk(hipGetLastError());
-    }
-    // ---- wavenet_split (wn_split.hpp) -------------------------------------------------------------
-    using SC1 = wn::SCfg<R, S, A, 1>;     // stream constants do not depend on BT
-    static constexpr bool SPLIT_SHAPE = F16 && SC1::SUPPORTED && wn::split_built(R, S, A);
-    bool splitModelOk() const { return SPLIT_SHAPE && m_numLayers >= 6 && (m_numLayers & 1) == 0; }
-    template <int BT> size_t splitLds(int nEmb) const { return wn::SCfg<R, S, A, BT>::ldsBytes(m_numLayers, nEmb); }
-    template <int BT> int splitEmb() const { return splitLds<BT>(1) <= kLdsMax ? 1 : 0; }
-    template <int BT> bool splitFits() const { return splitLds<BT>(0) <= kLdsMax; }
-    // a matrix into the role streams: device source, position in fragments inside each wave's stream
-    void packSplit(size_t frag, const float* dsrc, int M, int K, int nw, int firstWave, int gateRT, int hiWave = 0x7fffffff,
-                   size_t hiFrags = 0) {
-        const size_t stride = SC1::waveStrideFrags(m_numLayers) * C::FRAG_ELEMS;
-        hipLaunchKernelGGL((wn::pack_weight_kernel<F16>), dim3(gridFor((size_t)M * K)), dim3(256), 0, 0,
-                           m_wsplit + (size_t)firstWave * stride + frag * C::FRAG_ELEMS, dsrc, M, K, nw, stride, gateRT, hiWave,
-                           hiFrags * C::FRAG_ELEMS);
-        gpuErrChk(hipGetLastError());
-    }
-    bool isSplit() const { return m_org >= NVW_ORG_SPLIT && m_org <= NVW_ORG_SPLIT3; }
-    int splitTiles(int tiles) const {
-        return m_org == NVW_ORG_SPLIT ? (tiles > 2 * m_numCUs ? 3 : tiles > m_numCUs ? 2 : 1) : m_org - NVW_ORG_SPLIT1 + 1;
-    }
-    // production launches of a model the kernel supports; everything else (activation dump, fp32 tensors read in place,
-    // odd layer counts) runs on wavenet_wg
-    bool useSplit(const wn::Params& p) const { return isSplit() && m_wsplit && !p.dump && p.condRawKind != 1; }
-    template <int BT, bool EMB, int RAW> bool launchSplitK(wn::Params& p, int tiles, hipStream_t stream) {
-        if constexpr (SPLIT_SHAPE) {
-            const int grid = (tiles + BT - 1) / BT;
-            hipLaunchKernelGGL((wn::wavenet_split<R, S, A, BT, EMB, RAW>), dim3(grid), dim3(512), splitLds<BT>(EMB ? 1 : 0), stream, p);
-            return hipGetLastError() == hipSuccess;
-        }
-        return false;
-    }
-    template <int BT> bool launchSplitB(wn::Params& p, int tiles, hipStream_t stream) {
-        const bool emb = splitEmb<BT>() != 0;
-        p.embLds = emb ? 1 : 0;
-        if (p.condRawKind == 2) return emb ? launchSplitK<BT, true, 2>(p, tiles, stream) : launchSplitK<BT, false, 2>(p, tiles, stream);
-        return emb ? launchSplitK<BT, true, 0>(p, tiles, stream) : launchSplitK<BT, false, 0>(p, tiles, stream);
-    }
-    bool launchSplit(wn::Params& p, int tiles, hipStream_t stream) {
-        const int bt = splitTiles(tiles);
-        return bt == 3 ? launchSplitB<3>(p, tiles, stream) : bt == 2 ? launchSplitB<2>(p, tiles, stream) : launchSplitB<1>(p, tiles, stream);
-    }
-    template <int BT, bool EMB, int RAW> void allowSplitK() {
-        if constexpr (SPLIT_SHAPE) {
-            const size_t need = splitLds<BT>(EMB ? 1 : 0);
-            if (need <= kLdsMax)
-                gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_split<R, S, A, BT, EMB, RAW>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-        }
-    }
-    template <int BT> void allowSplit() {
-        allowSplitK<BT, false, 0>();
-        allowSplitK<BT, true, 0>();
-        allowSplitK<BT, false, 2>();
-        allowSplitK<BT, true, 2>();
     }
     void convertTo(elem* dst, const float* src, size_t n) {
         const float* d = onDevice(src, n);
@@ -325,7 +262,6 @@ protected:
         }
         if (org == NVW_ORG_CHAIN && !chainFits(chainLpcMax(m_numLayers), tiles)) org = singleOrg(tiles);
         if (org == NVW_ORG_CHAIN1 && !(CC::SUPPORTED && chainFits(1, tiles))) org = singleOrg(tiles);
-        if (org >= NVW_ORG_SPLIT && org <= NVW_ORG_SPLIT3 && !(splitModelOk() && splitFits<3>())) org = NVW_ORG_WG;
         m_org = org;
         m_chainLpc = org == NVW_ORG_CHAIN ? chainLpcMax(m_numLayers) : org == NVW_ORG_CHAIN1 ? 1 : 0;
         m_chainStages = m_chainLpc ? chainStagesFor(m_numLayers, m_chainLpc) : 0;
@@ -338,10 +274,9 @@ protected:
         return false;
     }
     int wgTiles(int tiles) const {
-        const bool byBatch = m_org == NVW_ORG_WG || isSplit();
-        const bool three = m_org == NVW_ORG_WG3 || (byBatch && tiles > 2 * m_numCUs);
+        const bool three = m_org == NVW_ORG_WG3 || (m_org == NVW_ORG_WG && tiles > 2 * m_numCUs);
         if (three && wg3Fits()) return 3;
-        const bool two = three || m_org == NVW_ORG_WG2 || (byBatch && tiles > m_numCUs);
+        const bool two = three || m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs);
         return (two && ldsFits<2>()) ? 2 : 1;
     }
 
@@ -350,7 +285,7 @@ public:
                    bool tanhEmbed = true, int organisation = NVW_ORG_AUTO)
         : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
-          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_wsplit(NULL), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0),
+          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0),
           m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0), m_ringShadow(NULL), m_histShadow(NULL),
           m_chainTimeoutTicks(wn::kChainTimeoutTicks), m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL),
           m_mulaw(NULL), m_pcmUser(NULL), m_pcmUserElems(0), m_stageUsed(0) {
@@ -376,7 +311,7 @@ public:
         // exactly the tiles of the batch
         {
             const int tiles = (batchSize + 15) / 16;
-            const int group = isChain() ? 1 : isSplit() ? 6 : wgTiles(tiles);   // (split: its own 1 / 2 / 3 or wavenet_wg's)
+            const int group = isChain() ? 1 : wgTiles(tiles);
             m_tiles = (tiles + group - 1) / group * group;
         }
 
@@ -394,11 +329,6 @@ public:
         const size_t wElems = (size_t)C::NW * C::waveStreamFrags(numLayers) * C::FRAG_ELEMS;
         gpuErrChk(hipMalloc(&m_wblob, wElems * sizeof(elem)));
         gpuErrChk(hipMemset(m_wblob, 0, wElems * sizeof(elem)));
-        if (isSplit()) {
-            const size_t sElems = (size_t)8 * SC1::waveStrideFrags(numLayers) * C::FRAG_ELEMS;
-            gpuErrChk(hipMalloc(&m_wsplit, sElems * sizeof(elem)));
-            gpuErrChk(hipMemset(m_wsplit, 0, sElems * sizeof(elem)));
-        }
         const size_t bElems = (size_t)numLayers * C::BIAS_L + 2 * A;
         gpuErrChk(hipMalloc(&m_bias, bElems * sizeof(float)));
         gpuErrChk(hipMemset(m_bias, 0, bElems * sizeof(float)));
@@ -459,18 +389,12 @@ public:
                 if constexpr (WG3) allowLds<3>();
             }
         }
-        if (m_wsplit) {
-            allowSplit<1>();
-            allowSplit<2>();
-            allowSplit<3>();
-        }
         gpuErrChk(hipDeviceSynchronize());
     }
 
     virtual ~nvWavenetInfer() {
         gpuErrChk(hipDeviceSynchronize());
         gpuErrChk(hipFree(m_wblob));
-        if (m_wsplit) gpuErrChk(hipFree(m_wsplit));
         gpuErrChk(hipFree(m_bias));
         gpuErrChk(hipFree(m_embedPrev));
         gpuErrChk(hipFree(m_embedCur));
@@ -536,29 +460,14 @@ public:
                            (int)C::streamPos(layer, C::O_PREV, m_numLayers), (int)C::streamPos(layer, C::O_CUR, m_numLayers),
                            (int)C::streamPos(layer, C::O_RES, m_numLayers), (int)C::streamPos(layer, C::O_SKIP, m_numLayers));
         gpuErrChk(hipGetLastError());
-        if (m_wsplit) {
-            // role A waves 0..3: cur | res;  role B waves 4..7: prev | skip, in the order role B consumes them
-            packSplit(SC1::posCur(layer), src.Wcur, 2 * R, R, 4, 0, R / 16);
-            packSplit(SC1::posRes(layer), src.Wres, R, R, 4, 0, 0);
-            packSplit(SC1::posPrev(layer, m_numLayers), src.Wprev, 2 * R, R, 4, 4, R / 16);
-            packSplit(SC1::posSkip(layer, m_numLayers), src.Wskip, S, R, 4, 4, 0);
-        }
         gpuErrChk(hipStreamSynchronize(0));
     }
     // col-major Wzs AxS, Bzs A, Wza AxA, Bza A (nv_wavenet.cuh:410-415)
     virtual void setOutWeights(float* Wzs, float* Bzs, float* Wza, float* Bza) {
         stageBegin((size_t)A * S + (size_t)A * A + 16);
         const size_t hf = C::headOffsetFrags(m_numLayers);
-        Wzs = (float*)onDevice(Wzs, (size_t)A * S);
-        Wza = (float*)onDevice(Wza, (size_t)A * A);
         packWeight(hf + C::O_ZS, Wzs, A, S, 0);
         packWeight(hf + C::O_ZA, Wza, A, A, 0);
-        if (m_wsplit) {
-            // eight-way split of the output rows; the head sits behind L layers of FLA (role A) or FLB (role B) fragments
-            const size_t ha = SC1::headOffA(m_numLayers), hb = SC1::headOffB(m_numLayers);
-            packSplit(ha + SC1::O_ZS, Wzs, A, S, 8, 0, 0, 4, hb - ha);
-            packSplit(ha + SC1::O_ZA, Wza, A, A, 8, 0, 0, 4, hb - ha);
-        }
         gpuErrChk(hipMemcpyAsync(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault, 0));
         gpuErrChk(hipMemcpyAsync(headBias() + A, Bza, A * sizeof(float), hipMemcpyDefault, 0));
         gpuErrChk(hipStreamSynchronize(0));
@@ -700,14 +609,6 @@ public:
                      CC::ldsBytes());
             return;
         }
-        if (isSplit() && m_wsplit && !dumpActivations && !(m_condRaw && m_condRawKind == 1)) {
-            const int sbt = splitTiles(tiles);
-            const int emb = sbt == 3 ? splitEmb<3>() : sbt == 2 ? splitEmb<2>() : splitEmb<1>();
-            const size_t slds = sbt == 3 ? splitLds<3>(emb) : sbt == 2 ? splitLds<2>(emb) : splitLds<1>(emb);
-            snprintf(buf, n, "wn::wavenet_split<fp16,%d,%d,%d,BT=%d,EMBLDS=%d,RAW=%d> tiles/wg=%d wgs=%d lds=%zu", R, S, A, sbt, emb,
-                     m_condRaw ? m_condRawKind : 0, sbt, (tiles + sbt - 1) / sbt, slds);
-            return;
-        }
         const int bt = wgTiles(tiles);
         int nEmb = bt == 2 ? embTables<2>() : embTables<1>();
         size_t lds = bt == 2 ? ldsNeed<2>(m_numLayers, nEmb) : ldsNeed<1>(m_numLayers, nEmb);
@@ -818,7 +719,6 @@ public:
 
         wn::Params p;
         p.wblob = m_wblob;
-        p.wsplit = m_wsplit;
         p.bias = m_bias;
         p.embPrev = m_embedPrev;
         p.embCur = m_embedCur;
@@ -866,14 +766,12 @@ public:
             }
             p.dil[m_numLayers] = p.dil[0];
             p.dil[m_numLayers + 1] = p.dil[1];
-            p.dil[m_numLayers + 2] = p.dil[2];
-            p.dil[m_numLayers + 3] = p.dil[3 < m_numLayers ? 3 : 0];
         }
         m_lastStride = num_samples;
         if (p.count <= 0) return true;
 
         const int tiles = (batch_size + 15) / 16;
-        bool result = isChain() ? launchChain(p, tiles, stream) : useSplit(p) ? launchSplit(p, tiles, stream) : launchWg(p, tiles, stream);
+        bool result = isChain() ? launchChain(p, tiles, stream) : launchWg(p, tiles, stream);
         if (m_pcmUser != NULL) {
             // the indices of a finished sample are final: the expansion is a per-element map of yOut
             hipLaunchKernelGGL(wn::mulaw_pcm_kernel, dim3(gridFor((size_t)batch_size * p.count)), dim3(256), 0, stream,

@@ -236,7 +236,6 @@ WN_DEV Dil dil_next(Dil s, int maxDilation, bool wrapToFirst) {
 // Everything the kernel needs, passed by value (role of nv_wavenet_params, nv_wavenet.cuh:40-85).
 struct Params {
     const void* wblob;       // NW per-wave streams: [L][FLW] layer fragments | [FHW] head fragments
-    const void* wsplit;      // wavenet_split only: 8 per-wave streams, role A (cur | res) and role B (prev | skip), wn_split.hpp
     const float* bias;       // [L][BIAS_L] then Bzs[A], Bza[A]
     const void* embPrev;     // [A][R] T_data
     const void* embCur;      // [A][R] T_data
@@ -272,7 +271,7 @@ struct Params {
     int embLds;              // embedding tables held in LDS: 0 none, 1 current tap, 2 both
     int useRng;              // selectors drawn in-kernel (Philox4x32-10) instead of read from `sel`
     unsigned rngKey0, rngKey1;
-    Dil dil[kMaxLayers + 4]; // schedule of layer l; entries L .. L+3 repeat layers 0 .. 3 (of the next sample)
+    Dil dil[kMaxLayers + 2]; // schedule of layer l; entries L and L+1 repeat layers 0 and 1 (of the next sample)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1579,7 +1578,7 @@ static __global__ void mulaw_pcm_kernel(const int* __restrict__ yOut, short* __r
 // dst + w*waveStride is the start of this matrix inside wave w's stream; idx = element of the packed matrix.
 template <bool F16>
 WN_DEV void pack_weight_elem(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src, int M, int K,
-                             int NW, size_t waveStride, int gateRT, size_t idx, int hiWave = 0x7fffffff, size_t hiOffset = 0) {
+                             int NW, size_t waveStride, int gateRT, size_t idx) {
     constexpr int EPL = Prec<F16>::EPL, TPF = Prec<F16>::TPF;
     const int KF = K / (16 * TPF);
     const int tilesPerWave = M / 16 / NW;
@@ -1601,15 +1600,14 @@ WN_DEV void pack_weight_elem(typename Prec<F16>::elem* __restrict__ dst, const f
     const int k = (kf * TPF + (e >> 2)) * 16 + g * 4 + (e & 3);
     float v = src[(size_t)m + (size_t)k * M];
     if (gateRT > 0) v *= gate_prescale<F16>(m >= M / 2);    // gated 2R x R matrix: see gate1()
-    // (streams of waves >= hiWave hold this matrix hiOffset elements further on: wavenet_split's two roles)
-    dst[(size_t)w * waveStride + (w >= hiWave ? hiOffset : 0) + (idx % perWave)] = (typename Prec<F16>::elem)v;
+    dst[(size_t)w * waveStride + (idx % perWave)] = (typename Prec<F16>::elem)v;
 }
 template <bool F16>
 __global__ void pack_weight_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ src, int M,
-                                   int K, int NW, size_t waveStride, int gateRT, int hiWave = 0x7fffffff, size_t hiOffset = 0) {
+                                   int K, int NW, size_t waveStride, int gateRT) {
     const size_t n = (size_t)M * K;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)
-        pack_weight_elem<F16>(dst, src, M, K, NW, waveStride, gateRT, idx, hiWave, hiOffset);
+        pack_weight_elem<F16>(dst, src, M, K, NW, waveStride, gateRT, idx);
 }
 
 // One layer in one launch (setLayerWeights): the four matrices into the per-wave streams and the three

@@ -30,12 +30,7 @@ class Org:
     WG3 = 4         # three tiles per workgroup (fp16, R <= 64; else two)
     CHAIN = 5       # wn::wavenet_chain: multi-CU, weights resident, fewest CUs
     CHAIN1 = 6      # wn::wavenet_chain, one layer per CU
-    SPLIT = 7       # wn::wavenet_split: eight waves per workgroup in two roles (fp16, R = 64; else wavenet_wg), tiles by batch size
-    SPLIT1 = 8
-    SPLIT2 = 9
-    SPLIT3 = 10
-    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6, "split": 7, "split1": 8,
-               "split2": 9, "split3": 10}
+    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6}
 
 
 def supported_configs():
@@ -67,8 +62,8 @@ class WavenetEngine:
         self.precision = precision
         if isinstance(organisation, str) or organisation is None:
             organisation = Org.BY_NAME[organisation]
-        if organisation not in range(11):
-            raise ValueError("organisation must be 0..10")
+        if organisation not in range(7):
+            raise ValueError("organisation must be 0..6")
         self._h = lib.nvw_create_ex(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
                                     1 if tanhEmbed else 0, organisation)
         if not self._h:

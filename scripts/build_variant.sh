@@ -7,5 +7,5 @@ name=$1; shift
 here=$(cd "$(dirname "$0")/.." && pwd)
 out=$here/scripts/ubench/bld_$name
 mkdir -p "$out"
-make -s -C "$here/nv_wavenet_amd/csrc" -j4 SHAPES=64_256_256 SPLIT_SHAPES=64_256_256 PRECS=16 EXTRA_INST= BLD="$out/obj" OUT="$out/libwavenet_infer.so" EXTRA="$*" 2>&1 | grep -E "error|warning: v" || true
+make -s -C "$here/nv_wavenet_amd/csrc" -j4 SHAPES=64_256_256 PRECS=16 EXTRA_INST= BLD="$out/obj" OUT="$out/libwavenet_infer.so" EXTRA="$*" 2>&1 | grep -E "error|warning: v" || true
 ls -la "$out/libwavenet_infer.so"
