@@ -198,6 +198,12 @@ void wavenet_infer(int sample_count, int batch_size, float* embedding_prev, floa
     assert(ok);
     (void)ok;
     gpuErrChk(hipDeviceSynchronize());
+    // a multi-CU launch that gave up is re-run on wavenet_wg in stream order; a code left here means that could not be done
+    // (this entry point has no status to return: fail like every other error of the path does, nv_wavenet_util.cuh:34-40)
+    if (const unsigned st = w->chainStatus()) {
+        fprintf(stderr, "wavenet_infer: multi-CU launch gave up (status 0x%x) and could not be re-run\n", st);
+        exit(1);
+    }
     delete w;
 }
 

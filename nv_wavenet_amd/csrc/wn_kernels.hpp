@@ -994,6 +994,16 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #ifndef WN_RAW_AUX
 #define WN_RAW_AUX 0
 #endif
+    // cache-policy bits of the ring loads / ring stores / packed-conditioning loads (2 = nt, streaming; experiments: 0, 1 = sc0, 16 = sc1)
+#ifndef WN_RING_LD_AUX
+#define WN_RING_LD_AUX 2
+#endif
+#ifndef WN_RING_ST_AUX
+#define WN_RING_ST_AUX 2
+#endif
+#ifndef WN_COND_AUX
+#define WN_COND_AUX 2
+#endif
     const size_t rawRow = (size_t)p.maxBatch * (2 * R) * RAWE;
     unsigned rawOff[BT];
 #pragma unroll
@@ -1017,7 +1027,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             if (k < KF_R) {                  // (one uniform branch, all tiles inside)
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++)
-                    xd[bt][i] = buf_load<frag, 2>(rsRing, laneOff, rp0 + (unsigned)bt * ringTileB + (unsigned)k * 1024u);
+                    xd[bt][i] = buf_load<frag, WN_RING_LD_AUX>(rsRing, laneOff, rp0 + (unsigned)bt * ringTileB + (unsigned)k * 1024u);
             }
         }
 #endif
@@ -1050,7 +1060,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             } else {
 #pragma unroll
                 for (int k = 0; k < C::COND_FR; k++)
-                    cdd[bt][k] = buf_load<frag, 2>(rsCond, laneOff + (unsigned)(k & 3) * 1024u,
+                    cdd[bt][k] = buf_load<frag, WN_COND_AUX>(rsCond, laneOff + (unsigned)(k & 3) * 1024u,
                                                    (unsigned)((bt * NW * C::COND_FR + (k & ~3)) * 1024));
             }
 #else
@@ -1234,7 +1244,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     if (k % NW == w) {       // (one uniform branch per fragment index, all tiles inside)
 #pragma unroll
                         for (int bt = 0; bt < BT; bt++)
-                            buf_store<frag, 2>(rsRing, laneOff + (unsigned)(k & 3) * 1024u,
+                            buf_store<frag, WN_RING_ST_AUX>(rsRing, laneOff + (unsigned)(k & 3) * 1024u,
                                                rp + (unsigned)bt * ringTileB + (unsigned)(k & ~3) * 1024u, xb[bt][k]);
                     }
             }
