@@ -346,7 +346,7 @@ template <bool F16> WN_DEV float tanh_t(float x) { return x; }
 // -- so the gate is exp2 / rcp with no multiplications in front:
 //     tanh(a) = 1 - 2 / (2^a' + 1),   sigmoid(b) = 1 / (1 + 2^b').
 // (Tried and slower on MI355X: the gate as one rational function with a single reciprocal, (7,6) Pade
-// approximant of tanh: 1770 vs 1470 clk per layer in wavenet_stream -- the extra FMAs cost more than
+// approximant of tanh: 1770 vs 1470 clk per layer in round 1's loader / consumer kernel -- the extra FMAs cost more than
 // the transcendentals they save; a lone wave issues a v_exp_f32 every 8.9 clk, a v_fma_f32 every 5.8.)
 template <bool F16> __host__ __device__ constexpr float gate_prescale(bool sigmoidRow) {
     return !F16 ? 1.0f : sigmoidRow ? -1.44269504088896340736f : 2.88539008177792681472f;

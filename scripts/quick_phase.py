@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase shader-clock breakdown of wavenet_wg / wavenet_stream (needs the WN_TIMING experiment build via NVW_LIB).
+"""Per-phase shader-clock breakdown of wavenet_wg (needs the WN_TIMING experiment build via NVW_LIB).
 usage: quick_phase.py [batch] [samples] [organisation: 2 = wg one tile (default), 3 = two tiles, 4 = three tiles]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
