@@ -178,6 +178,16 @@ def steady_engine(w, B, n_timed, seed=11, in_place=None, organisation=0):
         e.resetHistory()
         for first in range(0, N, COND_BLOCK):
             e.packConditioning(block[:min(COND_BLOCK, N - first)], first, min(COND_BLOCK, N - first))
+    elif in_place == "fragments":
+        # the caller's own buffer in the engine's fragment order (what a model's conditioning convolution emits with the
+        # channel permutation and the gate pre-scale folded into its weights: nv_wavenet.py get_cond_input(layout="packed"))
+        from nv_wavenet_amd.nv_wavenet import pack_cond_input
+        tiles = e.condTiles()
+        keep = torch.zeros(N + 1, L, tiles, 2 * R // 32, 4, 16, 8, dtype=torch.float16, device="cuda")
+        for first in range(0, N, COND_BLOCK):
+            n = min(COND_BLOCK, N - first)
+            keep[first:first + n].copy_(pack_cond_input(block[:n], 16, tiles)[:n])
+        e.setConditioningPacked(keep, N)
     else:
         keep = torch.empty(N, L, B, 2 * R, dtype=in_place, device="cuda")
         for first in range(0, N, COND_BLOCK):
@@ -538,14 +548,18 @@ def main():
         # engine's T_data) or fp32; steady state like the headline, at the headline batch, then at two / one tile per CU
         # until it is real time
         e2e["in_place"] = {}
-        for name, dt in (("fp16_tensor", torch.float16), ("fp32_tensor", torch.float32)):
+        for name, dt in (("fragment_order", "fragments"), ("fp16_tensor", torch.float16), ("fp32_tensor", torch.float32)):
             ip_sweep = {}
             for cand in [B] + [c for c in (32 * ncu, 16 * ncu) if c < B]:
                 k_ip, info_ip = measure_steady_khz(w, cand, in_place=dt)
                 ip_sweep[str(cand)] = k_ip
                 if k_ip >= REALTIME_KHZ:
                     break
-            e2e["in_place"][name] = {"definition": "conditioning %s [N][L][B][2R] in HBM read in place by the generation kernel "
+            e2e["in_place"][name] = {"definition": ("conditioning PRODUCED by the caller in the engine's fragment order (fp16; a model folds the "
+                                                    "channel permutation and the gate pre-scale into its conditioning convolution), used in place by "
+                                                    "the packed path of the generation kernel (nvw_set_conditioning_packed): no copy, no second "
+                                                    "pass, no conversion; samples 640..1151") if dt == "fragments" else
+                                                   "conditioning %s [N][L][B][2R] in HBM read in place by the generation kernel "
                                                    "(nvw_set_conditioning_direct_t): no packed copy, no second pass; samples 640..1151" % name,
                                      "batch_per_gpu": cand, "khz_per_utterance": k_ip, "kernel": info_ip.split(" ")[0],
                                      "real_time": bool(k_ip >= REALTIME_KHZ), "sweep_khz": ip_sweep}

@@ -89,6 +89,14 @@ void nvw_set_conditioning_direct(nvw_engine* e, float* Lh, int num_samples);
  * T_data: the reference keeps its conditioning in T_data, nv_wavenet.cuh:326; half the bytes of the fp32 tensor).  Returns 0
  * (and changes nothing) when the engine cannot read that element type in place. */
 int nvw_set_conditioning_direct_t(nvw_engine* e, const void* Lh, int num_samples, int precision);
+/* Conditioning PRODUCED in the engine's own fragment order by the caller (device memory, the engine's T_data):
+ * [num_samples + 1][L][nvw_cond_tiles(e)][wave][fragment][lane][8 (fp16) | 4 (fp32)] with the gate rows pre-scaled, i.e. what
+ * nvw_pack_conditioning writes (order: pack_cond_tiled_kernel in wn_kernels.hpp; nv_wavenet_amd/nv_wavenet.py:cond_fragment_order
+ * gives it as a channel permutation + scale, which a model folds into its conditioning convolution for free).  The generation
+ * kernels run their packed path on that buffer: no copy, no second pass.  One padding sample past the last; the buffer stays
+ * alive and unchanged until the run calls that follow have completed.  Resets the history like nvw_set_inputs. */
+void nvw_set_conditioning_packed(nvw_engine* e, const void* frags, int num_samples);
+int nvw_cond_tiles(nvw_engine* e);
 /* the selector half of nvw_set_inputs ([num_samples][batch] uniform draws, host or device); conditioning and history untouched */
 void nvw_set_selectors(nvw_engine* e, float* output_selectors, int num_samples);
 /* Multi-CU (wavenet_chain) launches need all their workgroups resident at once; when other work holds CUs a launch gives up

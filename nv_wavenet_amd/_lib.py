@@ -38,6 +38,8 @@ SIGNATURES = {
     "nvw_pack_conditioning": (None, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_void_p]),
     "nvw_set_conditioning_direct": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_set_conditioning_direct_t": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
+    "nvw_set_conditioning_packed": (None, [C.c_void_p, _fp, C.c_int]),
+    "nvw_cond_tiles": (C.c_int, [C.c_void_p]),
     "nvw_set_selectors": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_chain_status": (C.c_uint, [C.c_void_p]),
     "nvw_chain_fallbacks": (C.c_uint, [C.c_void_p]),

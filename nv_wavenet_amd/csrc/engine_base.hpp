@@ -14,6 +14,8 @@ struct nvw_engine {
     virtual void setConditioning(float*, int) = 0;
     virtual void packConditioning(float*, int, int, hipStream_t) = 0;
     virtual void setConditioningDirect(const void*, int, int) = 0;
+    virtual void setConditioningPacked(const void*, int) = 0;
+    virtual int condTiles() = 0;
     virtual void setSelectors(float*, int) = 0;
     virtual bool run_range(int, int, int, int, hipStream_t) = 0;
     virtual void resetHistory(hipStream_t) = 0;
@@ -52,6 +54,8 @@ struct EngineImpl : nvw_engine {
     void setConditioning(float* Lh, int n) override { eng.setConditioning(Lh, n); }
     void packConditioning(float* Lh, int first, int count, hipStream_t s) override { eng.packConditioning(Lh, first, count, s); }
     void setConditioningDirect(const void* Lh, int n, int prec) override { eng.setConditioningDirect(Lh, n, prec); }
+    void setConditioningPacked(const void* frags, int n) override { eng.setConditioningPacked(frags, n); }
+    int condTiles() override { return eng.condTiles(); }
     void setSelectors(float* sel, int n) override { eng.setSelectors(sel, n); }
     bool run_range(int i, int c, int n, int b, hipStream_t s) override { return eng.run_range(i, c, n, b, s); }
     void resetHistory(hipStream_t s) override { eng.resetHistory(s); }

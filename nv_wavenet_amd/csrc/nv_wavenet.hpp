@@ -94,6 +94,7 @@ protected:
     int m_condRawSamples;
     const void* m_condRaw;    // or: the caller's [N][L][maxBatch][2R] device tensor, consumed in place (setConditioningDirect)
     int m_condRawKind;        // 1: fp32, 2: fp16 (T_data of the fp16 engine)
+    const void* m_condUser;   // or: the caller's device buffer ALREADY in the engine's fragment order (setConditioningPacked)
     float* m_outputSelectors;
     elem* m_ring;
     int *m_yInPrev, *m_yInCur, *m_yOut;
@@ -285,7 +286,7 @@ public:
                    bool tanhEmbed = true, int organisation = NVW_ORG_AUTO)
         : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
-          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0),
+          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0), m_condUser(NULL),
           m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0), m_ringShadow(NULL), m_histShadow(NULL),
           m_chainTimeoutTicks(wn::kChainTimeoutTicks), m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL),
           m_mulaw(NULL), m_pcmUser(NULL), m_pcmUserElems(0), m_stageUsed(0) {
@@ -503,6 +504,7 @@ public:
         assert(firstSample >= 0 && count > 0 && firstSample + count <= m_maxSamples);
         m_condRaw = NULL;
         m_condRawKind = 0;
+        m_condUser = NULL;
         const size_t rows = (size_t)count * m_numLayers;
         const size_t srcPerRow = (size_t)m_maxBatch * 2 * R;
         const size_t dstPerRow = (size_t)m_tiles * 16 * 2 * R;
@@ -552,7 +554,26 @@ public:
         m_condRaw = Lh;
         m_condRawKind = precision == 16 ? 2 : 1;
         m_condRawSamples = numSamples;
+        m_condUser = NULL;
     }
+    // Conditioning that the caller has PRODUCED in the engine's own fragment order (round 3): T_data
+    // [numSamples + 1][L][condTiles()][wave][fragment][lane][EPL], gate rows pre-scaled -- exactly what packConditioning writes
+    // (pack_cond_tiled_kernel documents the order; nv_wavenet_amd/nv_wavenet.py: cond_fragment_order / get_cond_input(layout=
+    // "packed") produce it from the model's conditioning convolution by permuting and scaling that convolution's output
+    // channels, i.e. for free).  The generation kernels then run their packed path on the caller's buffer: no copy, no second
+    // pass, no in-place conversions -- the headline kernel as it is.  The buffer holds one padding sample past the last (the
+    // prefetch reads ahead), stays alive and unchanged until the runs that follow have completed.  Resets the history.
+    void setConditioningPacked(const void* frags, int numSamples) {
+        assert(numSamples > 0 && numSamples <= m_maxSamples);
+        assert(isDevicePtr(frags));
+        resetHistory(0);
+        gpuErrChk(hipStreamSynchronize(0));
+        m_condRaw = NULL;
+        m_condRawKind = 0;
+        m_condUser = frags;
+    }
+    // tiles of 16 utterances per (sample, layer) row of the packed conditioning (the batch rounded up to whole workgroups)
+    int condTiles() const { return m_tiles; }
     bool conditioningInPlace() const { return m_condRaw != NULL; }
     // the selector half of setInputs: [numSamples][maxBatch] uniform draws (host or device), conditioning and history untouched
     void setSelectors(float* outputSelectors, int numSamples) {
@@ -711,7 +732,7 @@ public:
         assert(batch_size % batch_size_per_block == 0);
         assert(batch_size > 0 && batch_size <= m_maxBatch);
         assert(num_samples <= m_maxSamples);
-        assert(m_condRaw != NULL || m_cond != NULL);                       // some conditioning has been handed over
+        assert(m_condRaw != NULL || m_cond != NULL || m_condUser != NULL);  // some conditioning has been handed over
         assert(m_condRaw == NULL || num_samples <= m_condRawSamples);      // ... and the in-place tensor covers the run
         assert(m_pcmUser == NULL || m_pcmUserElems == 0 || m_pcmUserElems >= (size_t)batch_size * num_samples);
         if (m_implementation == SINGLE_BLOCK) assert(S <= 4 * R);
@@ -722,7 +743,7 @@ public:
         p.bias = m_bias;
         p.embPrev = m_embedPrev;
         p.embCur = m_embedCur;
-        p.cond = m_cond;
+        p.cond = m_condUser ? m_condUser : m_cond;
         p.condRaw = m_condRaw;
         p.condRawKind = m_condRaw ? m_condRawKind : 0;
         p.gate = NULL;

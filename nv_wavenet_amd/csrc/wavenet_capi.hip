@@ -94,6 +94,8 @@ int nvw_set_conditioning_direct_t(nvw_engine* e, const void* Lh, int num_samples
     e->setConditioningDirect(Lh, num_samples, precision);
     return 1;
 }
+void nvw_set_conditioning_packed(nvw_engine* e, const void* frags, int num_samples) { e->setConditioningPacked(frags, num_samples); }
+int nvw_cond_tiles(nvw_engine* e) { return e->condTiles(); }
 void nvw_set_selectors(nvw_engine* e, float* sel, int num_samples) { e->setSelectors(sel, num_samples); }
 unsigned nvw_chain_status(nvw_engine* e) { return e->chainStatus(); }
 unsigned nvw_chain_fallbacks(nvw_engine* e) { return e->chainFallbacks(); }

@@ -132,6 +132,26 @@ class WavenetEngine:
         self._cond_keep = Lh
         assert lib.nvw_set_conditioning_direct_t(self._h, addr(Lh), ns, bits)
 
+    def condTiles(self):
+        """Tiles of 16 utterances per (sample, layer) row of the packed conditioning (the batch rounded up to whole workgroups)."""
+        return int(lib.nvw_cond_tiles(self._h))
+
+    def setConditioningPacked(self, frags, numSamples=None):
+        """Conditioning already in the engine's fragment order: a contiguous CUDA tensor
+        [numSamples + 1][L][condTiles()][waves][fragments][64][8 fp16 | 4 fp32] of the engine's T_data with the gate rows
+        pre-scaled (nv_wavenet.py: pack_cond_input / get_cond_input(layout="packed") build it); used in place by the packed
+        path of the generation kernels -- no copy, no conversion.  Kept referenced here until the next conditioning call."""
+        import torch
+        assert hasattr(frags, "data_ptr") and frags.is_cuda and frags.is_contiguous(), "setConditioningPacked takes contiguous device tensors"
+        want = torch.float16 if self.precision == 16 else torch.float32
+        if frags.dtype != want:
+            raise TypeError("an fp%d engine reads %s fragments" % (self.precision, want))
+        ns = self.maxSamples if numSamples is None else int(numSamples)
+        assert 0 < ns <= self.maxSamples
+        assert frags.numel() == (ns + 1) * self.numLayers * self.condTiles() * 16 * 2 * self.R, "fragment tensor has the wrong size"
+        self._cond_keep = frags
+        lib.nvw_set_conditioning_packed(self._h, addr(frags), ns)
+
     def setSelectors(self, outputSelectors, numSamples=None):
         """The selector half of setInputs: [numSamples][maxBatch] uniform draws; conditioning and history untouched."""
         sel = _f32(outputSelectors)

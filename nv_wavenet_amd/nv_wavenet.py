@@ -104,8 +104,59 @@ class NVWaveNet:
         return samples
 
 
+def cond_fragment_order(R, precision=16):
+    """The engine's conditioning fragment order as a channel permutation: (perm, scale), both of length 2R.  Within one
+    (sample, layer, tile of 16 utterances) the packed conditioning is [wave][fragment][g][utterance j][e]; position
+    q = ((wave * fragments + fragment) * 4 + g) * EPL + e holds channel perm[q] of the reference's 2R gate channels (tanh rows
+    0..R-1, sigmoid rows R..2R-1), multiplied by scale[q] -- the gate's pre-scale of the fp16 engine (2 log2 e on tanh rows,
+    -log2 e on sigmoid rows: wn_kernels.hpp gate_prescale), 1 for fp32.  (Restates pack_cond_tiled_kernel's index arithmetic.)"""
+    import math
+    RT = R // 16
+    NW = 4 if RT >= 4 else RT
+    HTW = RT // NW
+    TPF, EPL = (2, 8) if precision == 16 else (1, 4)
+    CF = 2 * HTW // TPF
+    perm, scale = [], []
+    for w in range(NW):
+        for c in range(CF):
+            for g in range(4):
+                for e in range(EPL):
+                    it = c * TPF + (e >> 2)
+                    tile16 = w + NW * (it >> 1) + (it & 1) * RT
+                    ch = tile16 * 16 + g * 4 + (e & 3)
+                    perm.append(ch)
+                    scale.append(1.0 if precision != 16 else (-1.44269504088896340736 if ch >= R else 2.88539008177792681472))
+    assert sorted(perm) == list(range(2 * R))
+    return perm, scale
+
+
+def _fragments_from_ordered(x, tiles, dtype):
+    """x [N][L][B][2R] with the channels already in fragment order (and pre-scaled) -> the engine's packed tensor
+    [N + 1][L][tiles][wave][fragment][g][j][EPL] (one zero padding sample, utterances padded to whole tiles)."""
+    N, L, B, C2 = x.shape
+    EPL = 8 if dtype == torch.float16 else 4
+    out = torch.zeros(N + 1, L, tiles * 16, C2, dtype=dtype, device=x.device)
+    out[:N, :, :B] = x.to(dtype)
+    out = out.view(N + 1, L, tiles, 16, C2 // (4 * EPL), 4, EPL)          # [n][l][tile][j][wave*fragment][g][e]
+    return out.permute(0, 1, 2, 4, 5, 3, 6).contiguous()                    # [n][l][tile][wave*fragment][g][j][e]
+
+
+def pack_cond_input(cond_nlbc, precision, tiles):
+    """[samples][layers][batch][2R] conditioning (any float dtype, on the device) -> the engine's own fragment order, for
+    WavenetEngine.setConditioningPacked / NVWaveNetEngine.infer(layout="packed"): a gather of the channel axis, the gate's
+    pre-scale (fp16 engines), one cast, one permuting copy.  tiles = engine.condTiles()."""
+    R = cond_nlbc.size(3) // 2
+    perm, scale = cond_fragment_order(R, precision)
+    dtype = torch.float16 if precision == 16 else torch.float32
+    idx = torch.tensor(perm, device=cond_nlbc.device)
+    x = cond_nlbc.float().index_select(3, idx)
+    if precision == 16:
+        x = x * torch.tensor(scale, dtype=torch.float32, device=x.device)
+    return _fragments_from_ordered(x, tiles, dtype)
+
+
 def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, cond_weight, cond_bias, n_layers,
-                   layout="CBLN", dtype=None):
+                   layout="CBLN", dtype=None, precision=16, tiles=None):
     """WaveNet.get_cond_input (pytorch/wavenet.py:190-202) as a function of the module's tensors,
     run wherever `features` lives (the GPU): ConvTranspose1d upsampling, trimming of the
     (kernel - stride) transposed-convolution tail, the 1x1 `cond_layers` convolution.
@@ -113,12 +164,27 @@ def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, co
     [2R*n_layers][n_cond][1].  layout "CBLN" returns the reference's 2R x batch x layers x samples
     view; "NLBC" returns the engine's own [samples][layers][batch][2R] contiguous tensor, which
     NVWaveNetEngine.infer takes without a further permute/copy.  dtype=torch.float16 emits the conditioning in the fp16
-    engine's T_data (rounded once, here), which that engine then reads in place at half the bytes."""
+    engine's T_data (rounded once, here), which that engine then reads in place at half the bytes.
+    layout "packed" (round 3) emits the engine's own FRAGMENT order for an engine of `precision` bits whose condTiles() is
+    `tiles` (NVWaveNetEngine.cond_tiles): the channel permutation and the gate's pre-scale are folded into the weights of the
+    1x1 convolution -- its output channels simply come out in fragment order, scaled -- so the only extra work against "NLBC"
+    is none: one permuting copy either way, and the generation kernels then run their packed path on the result as it is."""
     import torch.nn.functional as F
     x = F.conv_transpose1d(features, upsample_weight, upsample_bias, stride=upsample_stride)
     cutoff = upsample_weight.size(2) - upsample_stride
     if cutoff > 0:
         x = x[:, :, :-cutoff]
+    if layout == "packed":
+        assert tiles is not None, "layout='packed' needs the engine's condTiles()"
+        C2 = cond_weight.size(0) // n_layers
+        perm, scale = cond_fragment_order(C2 // 2, precision)
+        idx = torch.tensor(perm, device=cond_weight.device)
+        sc = torch.tensor(scale, dtype=cond_weight.dtype, device=cond_weight.device)
+        w = cond_weight.view(n_layers, C2, cond_weight.size(1), 1).index_select(1, idx) * sc[None, :, None, None]
+        b = cond_bias.view(n_layers, C2).index_select(1, idx) * sc[None, :]
+        x = F.conv1d(x, w.reshape(n_layers * C2, cond_weight.size(1), 1), b.reshape(-1))
+        x = x.view(x.size(0), n_layers, C2, x.size(2)).permute(3, 1, 0, 2)            # [N][L][B][2R], fragment channel order
+        return _fragments_from_ordered(x, tiles, torch.float16 if precision == 16 else torch.float32)
     x = F.conv1d(x, cond_weight, cond_bias)
     x = x.view(x.size(0), n_layers, -1, x.size(2))          # [B][L][2R][N]
     if layout == "CBLN":
@@ -181,12 +247,21 @@ class NVWaveNetEngine(NVWaveNet):
             e.close()
         self._engines = {}
 
+    def cond_tiles(self, batch_size, sample_count, implementation=Impl.AUTO):
+        """condTiles() of the engine that infer() will use for this batch and utterance length (for layout "packed")."""
+        return self._engine(batch_size, sample_count, implementation).condTiles()
+
     def infer(self, cond_input, implementation=Impl.AUTO, seed=None, return_audio=False, layout="CBLN",
-              generator=None):
-        """cond_input: 2R x batch x layers x samples (layout "CBLN", the reference's) or
-        [samples][layers][batch][2R] contiguous (layout "NLBC", used in place).
+              generator=None, batch_size=None):
+        """cond_input: 2R x batch x layers x samples (layout "CBLN", the reference's),
+        [samples][layers][batch][2R] contiguous (layout "NLBC", read in place), or the engine's own fragment order
+        (layout "packed": get_cond_input(..., layout="packed") / pack_cond_input; batch_size must be given; the generation
+        kernels run their packed path on it, no copy and no conversion).
         seed: int -> selectors drawn in-kernel by Philox4x32-10; None -> torch.rand on the device.
         Returns int32 [batch][samples] (and int16 audio [batch][samples] when return_audio)."""
+        if layout == "packed":
+            assert batch_size is not None and cond_input.is_cuda and cond_input.is_contiguous()
+            return self._infer_packed(cond_input, batch_size, implementation, seed, return_audio, generator)
         if layout == "CBLN":
             assert tuple(cond_input.size()[0:3:2]) == (2 * self.R, self.num_layers), \
                 "Inputs are channels x batch x num_layers x samples; got %s" % (tuple(cond_input.size()),)
@@ -208,14 +283,28 @@ class NVWaveNetEngine(NVWaveNet):
         stream.synchronize()                # (the engine's own uploads run on its upload stream)
         # consumed in place from this tensor: no packed copy; it stays referenced until the run below has completed
         e.setConditioningDirect(cond_input, sample_count)
+        return self._generate(e, dev, stream, sample_count, batch_size, seed, return_audio, generator)
+
+    def _infer_packed(self, frags, batch_size, implementation, seed, return_audio, generator):
+        sample_count = frags.size(0) - 1
+        e = self._engine(batch_size, sample_count, implementation)
+        assert frags.size(2) == e.condTiles(), "packed conditioning for %d tiles, the engine expects %d" % (frags.size(2), e.condTiles())
+        dev = frags.device
+        stream = torch.cuda.current_stream(dev)
+        stream.synchronize()
+        e.setConditioningPacked(frags, sample_count)
+        return self._generate(e, dev, stream, sample_count, batch_size, seed, return_audio, generator)
+
+    def _generate(self, e, dev, stream, sample_count, batch_size, seed, return_audio, generator):
+        sptr = stream.cuda_stream
         if seed is None:
             sel = torch.rand(sample_count, batch_size, dtype=torch.float32, device=dev, generator=generator)
             stream.synchronize()
             e.setSelectors(sel, sample_count)
         else:
             e.setSelectorSeed(seed)
-        samples = torch.zeros(batch_size, sample_count, dtype=torch.int32, device=cond_input.device)
-        audio = torch.zeros(batch_size, sample_count, dtype=torch.int16, device=cond_input.device) \
+        samples = torch.zeros(batch_size, sample_count, dtype=torch.int32, device=dev)
+        audio = torch.zeros(batch_size, sample_count, dtype=torch.int16, device=dev) \
             if return_audio else None
         e.setAudioOut(audio)
         bspb = 4 if batch_size % 4 == 0 else 2 if batch_size % 2 == 0 else 1

@@ -425,6 +425,75 @@ def test_conditioning_consumed_in_place(mode, precision):
     e.close()
 
 
+@pytest.mark.parametrize("mode,precision", [("wg", 32), ("chain", 32), ("wg", 16), ("wg2", 16), ("wg3", 16), ("chain", 16)])
+def test_conditioning_produced_in_fragment_order(mode, precision):
+    """Round 3: conditioning the caller PRODUCES in the engine's fragment order (setConditioningPacked; a model folds the
+    channel permutation and the gate's pre-scale into its conditioning convolution, nv_wavenet.py: get_cond_input(layout=
+    "packed")): the generation kernels run their packed path -- the headline kernel as it is -- on the caller's buffer, no
+    copy, no second pass, no in-place conversion.  O(1) inputs, ragged batch, chunked.  fp32 (no pre-scale, no rounding): the
+    samples must be those of setInputs, bit for bit.  fp16: the producer rounds value * prescale to fp16 itself, so the
+    engine is held to the fp32 oracle fed exactly the values it was given (fragment / prescale) by util.fp16_bars, and the
+    buffer really is what is read (negating it changes the samples; the caller's tensor is not modified)."""
+    import torch
+    from nv_wavenet_amd.nv_wavenet import pack_cond_input, cond_fragment_order
+    case = cases.Case("C3_o1_B37", 31, [], cases.Shape(64, 256, 256, 20, 37, 40, 16), 3, 1, 16)
+    s = case.shape
+    t = util.gen_o1(case, half=(precision == 16))
+    e = _engine_o1(case, t, precision, mode)
+    _check_mode(e, mode, s, precision)
+    y_set_inputs = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, s.B, y_set_inputs, 1, False)
+    e.synchronize()
+    Lh = torch.from_numpy(t.Lh).cuda()
+    frags = pack_cond_input(Lh, precision, e.condTiles())
+    assert frags.shape[0] == s.N + 1 and frags.shape[2] == e.condTiles() and frags.numel() == (s.N + 1) * s.L * e.condTiles() * 16 * 2 * s.R
+    before = frags.clone()
+    e.setConditioningPacked(frags)
+    e.setSelectors(t.sel)
+    got = _run_dumped(e, case, chunk=16)
+    assert torch.equal(frags, before), "the caller's buffer was modified"
+    if precision == 32:
+        assert np.array_equal(got["y"], y_set_inputs), "fragment-order conditioning differs from setInputs in fp32"
+        ref = _teacher_forced_ref(case, t, got["y"])
+        assert np.array_equal(got["y"], ref["y"])
+        util.compare_activations(ref, got, atol_eps=32)
+    else:
+        # what the engine was given, as the oracle's conditioning: fragment value / prescale, back in channel order
+        perm, scale = cond_fragment_order(s.R, 16)
+        idx = torch.tensor(perm, device="cuda")
+        sc = torch.tensor(scale, dtype=torch.float32, device="cuda")
+        given = ((Lh.index_select(3, idx) * sc).half().float() / sc)
+        Lh_eff = torch.empty_like(Lh)
+        Lh_eff.index_copy_(3, idx, given)
+        import copy
+        t_eff = copy.copy(t)
+        t_eff.Lh = np.ascontiguousarray(Lh_eff.cpu().numpy())
+        ref = util.teacher_forced_oracle(case, t_eff, got["y"])
+        st = util.fp16_bars(ref, got, t.sel.T, "fragment order %s" % mode)
+        print("fragment-order conditioning fp16 %s: %s; identical to setInputs: %.4f" %
+              (mode, {k: round(v, 4) for k, v in st.items()}, (got["y"] == y_set_inputs).mean()))
+        assert (np.abs(Lh_eff.cpu().numpy() - t.Lh).max() <= 2.0 ** -10 * np.abs(t.Lh).max())     # the same conditioning to an fp16 ulp
+    # production kernels, one launch: the same samples
+    e.setConditioningPacked(frags)
+    e.setSelectors(t.sel)
+    y = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, s.B, y, 1, False)
+    e.synchronize()
+    assert e.chainStatus() == 0 and np.array_equal(y, got["y"])
+    # the buffer is what is read
+    neg = (-frags).contiguous()
+    e.setConditioningPacked(neg)
+    e.setSelectors(t.sel)
+    y2 = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, s.B, y2, 1, False)
+    e.synchronize()
+    assert (y2 != y).mean() > 0.5
+    if precision == 32:
+        with pytest.raises(TypeError):
+            e.setConditioningPacked(frags.half())
+    e.close()
+
+
 @pytest.mark.parametrize("tiles_per_cu", [2, 3])
 def test_benchmarked_launch_is_the_parity_tested_one(tiles_per_cu):
     """What bench.py times by default IS pinned: C3 at BASELINE depth and dilation range (R64/S256/A256, 20 layers,
@@ -646,7 +715,7 @@ def test_python_wrapper_fp16_conditioning_in_place_and_get_cond_input():
     place (RAW=2 kernels, no fp32 detour, no packed copy), and the samples equal those from the fp32 tensor holding the
     same (fp16-representable) values."""
     import torch
-    from nv_wavenet_amd.nv_wavenet import NVWaveNetEngine, Impl, get_cond_input
+    from nv_wavenet_amd.nv_wavenet import NVWaveNetEngine, Impl, get_cond_input, pack_cond_input
     R, S, A, L, B, frames, stride, n_cond = 64, 256, 256, 6, 5, 6, 8, 20
     w, dev, _ = _wrapper_model(R, S, A, L, B, 8, seed=13)
     gen = torch.Generator().manual_seed(3)
@@ -668,6 +737,17 @@ def test_python_wrapper_fp16_conditioning_in_place_and_get_cond_input():
     assert torch.equal(y16, y32) and y16.shape == (B, N) and int(torch.unique(y16).numel()) > 8
     yc = model.infer(c16, Impl.PERSISTENT, seed=11, layout="NLBC")                   # the chain reads it in place as well
     assert torch.equal(yc, y16)
+    # round 3: the conditioning convolution emits the engine's FRAGMENT order itself (channel permutation and gate pre-scale
+    # folded into its weights): the packed path of the generation kernels runs on that tensor, no in-place conversion
+    tiles = model.cond_tiles(B, N, Impl.SINGLE_BLOCK)
+    cp = get_cond_input(feats, up_w, up_b, stride, cw, cb, L, layout="packed", precision=16, tiles=tiles)
+    assert cp.dtype == torch.float16 and cp.is_contiguous() and cp.shape[0] == N + 1 and cp.shape[2] == tiles
+    assert cp.numel() == (N + 1) * L * tiles * 16 * 2 * R and float(cp[N].abs().max()) == 0.0
+    assert torch.equal(cp, pack_cond_input(ref.permute(3, 2, 1, 0), 16, tiles)) or \
+        float((cp.float() - pack_cond_input(ref.permute(3, 2, 1, 0), 16, tiles).float()).abs().max()) <= 2.0 ** -9 * float(cp.abs().max())
+    yp = model.infer(cp, Impl.SINGLE_BLOCK, seed=11, layout="packed", batch_size=B)
+    assert "RAW=0" in e.kernelInfo(B, False), e.kernelInfo(B, False)
+    assert yp.shape == (B, N) and float((yp == y16).float().mean()) > 0.5      # same network, conditioning equal to an fp16 ulp
     model.close()
 
 
