@@ -1292,7 +1292,10 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         // from here that is behind the rest of the gate, both exchanges and the residual GEMM, the longest
                         // such stretch of a layer (issued right behind the current-tap GEMM instead: 34.2 instead of
                         // 31.7 us per sample at 8192 utterances, 41.9 instead of 39.7 at 12 288).
-                        if constexpr (gi == (STW * KF_R / G) * 3 / 4) {
+#ifndef WN_REQ_AT
+#define WN_REQ_AT 6          // eighths of the skip GEMM behind which taps and conditioning are requested
+#endif
+                        if constexpr (gi == (STW * KF_R / G) * WN_REQ_AT / 8) {
                             prefetch(t, l + 2, dl2, xpC, cdC);
                             __builtin_amdgcn_sched_barrier(0);
                         }
