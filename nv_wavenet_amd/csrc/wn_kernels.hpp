@@ -1391,7 +1391,12 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(xbuf + bt * KF_R * 1024, lane, xb[bt]);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef WN_ABL_NOTAPGEMM      // timing experiment: the tap GEMM's fragments taken (the ring keeps turning), its MFMAs not issued
+            skip_frags<F16, PF, 0, ws_pin, 4>(ws, rsW, C::P_PREV - PB, wl, 0, laneOff);
+            (void)xp;
+#else
             gemm_b<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, rsW, C::P_PREV - PB, wl, 0, laneOff, acc, xp);
+#endif
         };
         {
             // schedule entries of layers l, l+1, l+2 (the latter two may be layers 0, 1 of the next sample: table entries L, L+1)
