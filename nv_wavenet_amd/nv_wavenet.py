@@ -253,8 +253,9 @@ class NVWaveNetEngine(NVWaveNet):
 
     def infer(self, cond_input, implementation=Impl.AUTO, seed=None, return_audio=False, layout="CBLN",
               generator=None, batch_size=None):
-        """cond_input: 2R x batch x layers x samples (layout "CBLN", the reference's),
-        [samples][layers][batch][2R] contiguous (layout "NLBC", read in place), or the engine's own fragment order
+        """cond_input: 2R x batch x layers x samples (layout "CBLN", the reference's: converted to the engine's fragment order
+        by the one permuting copy any layout change needs), [samples][layers][batch][2R] contiguous (layout "NLBC", read in
+        place), or the engine's own fragment order
         (layout "packed": get_cond_input(..., layout="packed") / pack_cond_input; batch_size must be given; the generation
         kernels run their packed path on it, no copy and no conversion).
         seed: int -> selectors drawn in-kernel by Philox4x32-10; None -> torch.rand on the device.
@@ -263,12 +264,19 @@ class NVWaveNetEngine(NVWaveNet):
             assert batch_size is not None and cond_input.is_cuda and cond_input.is_contiguous()
             return self._infer_packed(cond_input, batch_size, implementation, seed, return_audio, generator)
         if layout == "CBLN":
+            # the reference's layout: one permuting copy is needed whatever the engine reads, so it goes straight to the
+            # engine's fragment order (pack_cond_input) and the generation kernels run their packed path on it
             assert tuple(cond_input.size()[0:3:2]) == (2 * self.R, self.num_layers), \
                 "Inputs are channels x batch x num_layers x samples; got %s" % (tuple(cond_input.size()),)
-            cond_input = column_major(cond_input.contiguous())
-        else:
-            assert layout == "NLBC" and cond_input.is_contiguous() and \
-                tuple(cond_input.size()[1::2]) == (self.num_layers, 2 * self.R)
+            dev = self.conv_out.device
+            sample_count, batch_size = cond_input.size(3), cond_input.size(1)
+            e = self._engine(batch_size, sample_count, implementation)
+            frags = pack_cond_input(cond_input.to(device=dev).permute(3, 2, 1, 0), self.precision, e.condTiles())
+            stream = torch.cuda.current_stream(dev)
+            stream.synchronize()
+            e.setConditioningPacked(frags, sample_count)
+            return self._generate(e, dev, stream, sample_count, batch_size, seed, return_audio, generator)
+        assert layout == "NLBC" and cond_input.is_contiguous() and tuple(cond_input.size()[1::2]) == (self.num_layers, 2 * self.R)
         sample_count, batch_size = cond_input.size(0), cond_input.size(2)
         # the conditioning lives where the model lives (a host tensor is uploaded once, like the reference's setInputs
         # does); an fp16 engine reads an fp16 tensor as it is, everything else is consumed as fp32
@@ -279,7 +287,6 @@ class NVWaveNetEngine(NVWaveNet):
         # everything below is ordered on the caller's current stream of that device: the tensors above were produced
         # on it, the engine's launches go to it, and the results are consumed on it
         stream = torch.cuda.current_stream(dev)
-        sptr = stream.cuda_stream
         stream.synchronize()                # (the engine's own uploads run on its upload stream)
         # consumed in place from this tensor: no packed copy; it stays referenced until the run below has completed
         e.setConditioningDirect(cond_input, sample_count)
