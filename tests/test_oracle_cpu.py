@@ -47,6 +47,28 @@ def test_oracle_matches_reference_build_live(case):
     o.close(), r.close()
 
 
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (reference build) not present")
+@pytest.mark.parametrize("shape", [cases.Shape(64, 256, 256, 20, 16, 24, 8), cases.Shape(128, 256, 256, 30, 8, 12, 512),
+                                   cases.Shape(32, 128, 256, 8, 5, 40, 4)], ids=["C3", "C4", "R32_ragged"])
+def test_oracle_matches_reference_build_live_on_the_o1_recipe(shape):
+    """The same pin on inputs at the magnitudes of a trained network (tests/util.py: o1_recipe), where the samples depend on
+    every part of the network and the gate, the ReLUs and the softmax leave their linear range: the restatement and the
+    reference's own nv_wavenet_reference.cpp + matrix.cpp still agree bit for bit (samples and every activation)."""
+    case = cases.Case("o1_pin", 30, [], shape, 3, 1, shape.N)
+    s = case.shape
+    t = util.gen_o1(case, half=False)
+    o, r = util.make_oracle(case, t), O.RefOracle(s.L, s.B, s.N, s.R, s.S, s.A, s.maxD)
+    r.set_model(t)
+    r.set_inputs(t.Lh, t.sel)
+    y = o.run(s.N)
+    assert np.array_equal(y, r.run(s.N)) and len(np.unique(y)) > min(100, y.size // 3)
+    go, gr = o.getters(), r.getters()
+    for k in go:
+        assert np.array_equal(go[k], gr[k]), k
+    assert float(np.abs(go["Za"]).max()) > 0.3, "logits of order one"
+    o.close(), r.close()
+
+
 def test_oracle_chunked_equals_single_run_and_teacher_forcing():
     """run(a)+run(b) from one setInputs is NOT run(a+b) in the reference (sample index restarts, so
     the dilated history is logically cleared); teacher forcing with the oracle's own output
