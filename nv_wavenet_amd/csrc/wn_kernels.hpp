@@ -1010,14 +1010,16 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     for (int bt = 0; bt < BT; bt++) rawOff[bt] = ((unsigned)ub[bt] * (unsigned)(2 * R) + (unsigned)g * 4u) * RAWE;
     auto prefetch = [&](int tn, int ln, Dil dl, frag (&xd)[BT][XPW], frag (&cdd)[BT][CR]) {
         if (ln >= L) { ln -= L; tn += 1; }
-#ifdef WN_ABL_HOTLOADS      // timing experiment: taps and conditioning always from the same (L2-resident) addresses
+        // timing experiments: taps (WN_ABL_HOTTAPS) and / or conditioning (WN_ABL_HOTCOND) always from the same, L2-resident
+        // addresses; WN_ABL_HOTLOADS = both
+#if defined(WN_ABL_HOTLOADS) || defined(WN_ABL_HOTTAPS)
         const unsigned slot = (unsigned)(dl.off & 1);
-        const unsigned rp0 = slot * (unsigned)(KF_R * 1024);
-        const rsrc_t rsCond = make_rsrc(condNext);
 #else
         const unsigned slot = (unsigned)(dl.off + (tn & (dl.d - 1)));
+#endif
         const unsigned rp0 = slot * (unsigned)(KF_R * 1024);
         const rsrc_t rsCond = make_rsrc(condNext);
+#if !defined(WN_ABL_HOTLOADS) && !defined(WN_ABL_HOTCOND)
         condNext += condStride;
 #endif
 #ifndef WN_ABL_NOXP
