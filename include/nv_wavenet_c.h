@@ -109,6 +109,11 @@ unsigned nvw_chain_status(nvw_engine* e);
 unsigned nvw_chain_fallbacks(nvw_engine* e);
 unsigned nvw_chain_last_timeout(nvw_engine* e);
 void nvw_set_chain_timeout_ms(nvw_engine* e, double ms);
+/* Measurement aid: with the probe on, workgroup 0 of every single-workgroup-organisation launch records the shader-clock and the
+ * constant-rate wall-clock counters at its start and end; nvw_last_launch_clock_ghz returns shader ticks per wall second of the
+ * latest launch, i.e. the clock the chip granted it under its power budget (0 when nothing was probed); synchronises the device. */
+void nvw_set_clock_probe(nvw_engine* e, int on);
+double nvw_last_launch_clock_ghz(nvw_engine* e);
 /* Samples [init_sample, init_sample + count) of a num_samples-long utterance, asynchronously on `stream`
  * (one chunk of run_chunks, for hosts that drive the chunks themselves); nvw_reset_history puts the
  * sample history back to 128 like nvw_set_inputs does, without touching the conditioning. */

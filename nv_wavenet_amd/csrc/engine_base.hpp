@@ -24,6 +24,8 @@ struct nvw_engine {
     virtual unsigned chainFallbacks() = 0;
     virtual unsigned chainLastTimeout() = 0;
     virtual void setChainTimeoutMs(double) = 0;
+    virtual void setClockProbe(bool) = 0;
+    virtual double lastLaunchClockGHz() = 0;
     virtual int precisionBits() = 0;
     virtual int maxSamples() = 0;
     virtual void setSelectorSeed(unsigned long long) = 0;
@@ -64,6 +66,8 @@ struct EngineImpl : nvw_engine {
     unsigned chainFallbacks() override { return eng.chainFallbacks(); }
     unsigned chainLastTimeout() override { return eng.chainLastTimeout(); }
     void setChainTimeoutMs(double ms) override { eng.setChainTimeoutMs(ms); }
+    void setClockProbe(bool on) override { eng.setClockProbe(on); }
+    double lastLaunchClockGHz() override { return eng.lastLaunchClockGHz(); }
     int precisionBits() override { return std::is_same<Td, float>::value ? 32 : 16; }
     int maxSamples() override { return cap; }
     void setSelectorSeed(unsigned long long seed) override { eng.setSelectorSeed(seed); }

@@ -117,6 +117,8 @@ protected:
     short* m_mulaw;     // [A] PCM value of every sample index
     short* m_pcmUser;   // caller's buffer (host or device), filled wherever yOut is
     size_t m_pcmUserElems;   // its size in int16 values when the caller said so (0: unknown)
+    unsigned long long* m_clk;   // clock probe of the latest wavenet_wg launch (wn::Params::clk), when switched on
+    bool m_clkOn;
 
     static bool isDevicePtr(const void* ptr) {
         hipPointerAttribute_t attr;
@@ -289,7 +291,7 @@ public:
           m_num_samples_per_chunk(0), m_lastStride(numSamples), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0), m_condUser(NULL),
           m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0), m_ringShadow(NULL), m_histShadow(NULL),
           m_chainTimeoutTicks(wn::kChainTimeoutTicks), m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL),
-          m_mulaw(NULL), m_pcmUser(NULL), m_pcmUserElems(0), m_stageUsed(0) {
+          m_mulaw(NULL), m_pcmUser(NULL), m_pcmUserElems(0), m_clk(NULL), m_clkOn(false), m_stageUsed(0) {
         assert(numLayers >= 2 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
         assert(numLayers <= wn::kMaxLayers);
         {
@@ -417,6 +419,7 @@ public:
         if (m_stage) gpuErrChk(hipFree(m_stage));
         if (m_pcm) gpuErrChk(hipFree(m_pcm));
         if (m_mulaw) gpuErrChk(hipFree(m_mulaw));
+        if (m_clk) gpuErrChk(hipFree(m_clk));
     }
 
     // false: the shape does not fit this GPU's CUs in the chosen organisation; run() returns false
@@ -430,6 +433,28 @@ public:
     unsigned chainStatus() { return statusWord(0); }
     unsigned chainFallbacks() { return statusWord(2); }
     unsigned chainLastTimeout() { return statusWord(1); }
+    // Clock probe (measurement aid; wavenet_wg launches): workgroup 0 of every launch that follows records the shader-clock
+    // counter and the constant-rate wall-clock counter at its start and end.  lastLaunchClockGHz(): shader ticks per wall
+    // second of the latest launch = the clock the chip granted it under its power budget (0 when no launch was probed);
+    // synchronises the device.
+    void setClockProbe(bool on) {
+        if (on && !m_clk) {
+            gpuErrChk(hipMalloc(&m_clk, 4 * sizeof(unsigned long long)));
+            gpuErrChk(hipMemset(m_clk, 0, 4 * sizeof(unsigned long long)));
+        }
+        m_clkOn = on;
+    }
+    double lastLaunchClockGHz() {
+        if (!m_clk) return 0.0;
+        unsigned long long c[4];
+        gpuErrChk(hipDeviceSynchronize());
+        gpuErrChk(hipMemcpy(c, m_clk, sizeof(c), hipMemcpyDeviceToHost));
+        int dev = 0, wallKHz = 0;
+        gpuErrChk(hipGetDevice(&dev));
+        gpuErrChk(hipDeviceGetAttribute(&wallKHz, hipDeviceAttributeWallClockRate, dev));
+        if (c[3] <= c[1] || wallKHz <= 0) return 0.0;
+        return (double)(c[2] - c[0]) / (double)(c[3] - c[1]) * (double)wallKHz * 1e-6;
+    }
     // bound of every hand-off spin of the chain (default 1.5 s)
     void setChainTimeoutMs(double ms) { m_chainTimeoutTicks = (long long)(ms * 1e5); }
 
@@ -775,6 +800,7 @@ public:
         p.useRng = m_useRng ? 1 : 0;
         p.rngKey0 = (unsigned)m_rngSeed;
         p.rngKey1 = (unsigned)(m_rngSeed >> 32);
+        p.clk = m_clkOn ? m_clk : NULL;
         {
             // dilation schedule (nv_wavenet.cuh:99,110-111) as a table in the kernel arguments: dilation and first ring slot
             int d = 1, off = 0;

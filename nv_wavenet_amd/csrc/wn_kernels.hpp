@@ -271,6 +271,9 @@ struct Params {
     int embLds;              // embedding tables held in LDS: 0 none, 1 current tap, 2 both
     int useRng;              // selectors drawn in-kernel (Philox4x32-10) instead of read from `sel`
     unsigned rngKey0, rngKey1;
+    unsigned long long* clk; // when non-NULL: workgroup 0 leaves {shader clock, wall clock} at its start and {..} at its end here
+                             // (4 words): ticks of s_memtime over ticks of the constant-rate s_memrealtime = the clock the launch
+                             // actually ran at (the chip clocks to its power budget: MI355X_MICROARCH.md, DVFS)
     Dil dil[kMaxLayers + 2]; // schedule of layer l; entries L and L+1 repeat layers 0 and 1 (of the next sample)
 };
 
@@ -879,6 +882,10 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     const int g = lane >> 4, j = lane & 15;
     const int L = p.numLayers;
     const int tile0 = p.tileBase + blockIdx.x * BT;
+    if (p.clk != nullptr && blockIdx.x == 0 && tid == 0) {
+        p.clk[0] = __builtin_amdgcn_s_memtime();
+        p.clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
 
     // utterance of this lane in its MFMA role (column j of tile bt)
     int ub[BT];
@@ -1573,6 +1580,10 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 p.yInPrev[ub[bt]] = yPrev[bt];
                 p.yInCur[ub[bt]] = yCur[bt];
             }
+    }
+    if (p.clk != nullptr && blockIdx.x == 0 && tid == 0) {
+        p.clk[2] = __builtin_amdgcn_s_memtime();
+        p.clk[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

@@ -189,6 +189,14 @@ class WavenetEngine:
     def setChainTimeoutMs(self, ms):
         lib.nvw_set_chain_timeout_ms(self._h, float(ms))
 
+    def setClockProbe(self, on=True):
+        """Measurement aid: workgroup 0 of every wavenet_wg launch that follows records shader and wall clock counters."""
+        lib.nvw_set_clock_probe(self._h, 1 if on else 0)
+
+    def lastLaunchClockGHz(self):
+        """Shader clock the latest probed launch actually ran at (GHz; 0.0 if none was probed); synchronises."""
+        return float(lib.nvw_last_launch_clock_ghz(self._h))
+
     def kernelInfo(self, batch_size=None, dumpActivations=False):
         """The device code run(n, batch_size, ..., dumpActivations) launches (kernel + template arguments)."""
         import ctypes
