@@ -35,6 +35,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "wn_bcast.hpp"
 #include "wn_chain.hpp"
 #include "wn_kernels.hpp"
 
@@ -57,7 +58,11 @@ enum nvwOrganisation {
     NVW_ORG_WG3 = 4,      // wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64; else two)
     NVW_ORG_CHAIN = 5,    // wn::wavenet_chain, as many layers per CU as stay resident
     NVW_ORG_CHAIN1 = 6,   // wn::wavenet_chain, one layer per CU
-    NVW_ORG_LAST = NVW_ORG_CHAIN1
+    NVW_ORG_BCAST = 7,    // wn::wavenet_bcast: every wave runs the whole network for its own tiles, weights broadcast through an
+                          // LDS ring; one or two tiles per wave by batch size (R = 64 shapes; others run wavenet_wg)
+    NVW_ORG_BCAST1 = 8,   // ... exactly one tile per wave (4 per workgroup)
+    NVW_ORG_BCAST2 = 9,   // ... two tiles per wave (8 per workgroup; fp16)
+    NVW_ORG_LAST = NVW_ORG_BCAST2
 };
 
 template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
@@ -265,11 +270,29 @@ protected:
         }
         if (org == NVW_ORG_CHAIN && !chainFits(chainLpcMax(m_numLayers), tiles)) org = singleOrg(tiles);
         if (org == NVW_ORG_CHAIN1 && !(CC::SUPPORTED && chainFits(1, tiles))) org = singleOrg(tiles);
+        if (org >= NVW_ORG_BCAST && org <= NVW_ORG_BCAST2 && !bcastFits()) org = singleOrg(tiles);
         m_org = org;
         m_chainLpc = org == NVW_ORG_CHAIN ? chainLpcMax(m_numLayers) : org == NVW_ORG_CHAIN1 ? 1 : 0;
         m_chainStages = m_chainLpc ? chainStagesFor(m_numLayers, m_chainLpc) : 0;
     }
     bool isChain() const { return m_chainLpc > 0; }
+    // ---- wn::wavenet_bcast ------------------------------------------------------------------------------------------
+    static constexpr bool BC1 = wn::BCfg<F16, R, S, A, 1>::SUPPORTED;
+    static constexpr bool BC2 = F16 && wn::BCfg<F16, R, S, A, 2>::SUPPORTED;      // (two tiles per wave: the fp16 engine)
+    bool isBcast() const { return m_org >= NVW_ORG_BCAST && m_org <= NVW_ORG_BCAST2; }
+    template <int BTW> static size_t bcastLds(int L, bool dump, int emb) { return wn::BCfg<F16, R, S, A, BTW>::ldsBytes(L, dump, emb); }
+    // the shape has the kernel, the model is deep enough for its two-layer lookahead and its tables fit the LDS beside the ring
+    bool bcastFits() const {
+        if constexpr (BC1) return m_numLayers >= 3 && bcastLds<1>(m_numLayers, true, 0) <= kLdsMax;
+        return false;
+    }
+    // tiles per wave for a batch of `tiles` tiles
+    int bcastTiles(int tiles) const {
+        if constexpr (BC2) {
+            if (m_org == NVW_ORG_BCAST2 || (m_org == NVW_ORG_BCAST && tiles > 4 * m_numCUs)) return 2;
+        }
+        return 1;
+    }
     // tiles per workgroup of wn::wavenet_wg for a batch of `tiles` tiles
     static constexpr bool WG3 = F16 && R <= 64;   // shapes with a three-tile instantiation
     bool wg3Fits() const {
@@ -314,7 +337,7 @@ public:
         // exactly the tiles of the batch
         {
             const int tiles = (batchSize + 15) / 16;
-            const int group = isChain() ? 1 : wgTiles(tiles);
+            const int group = isChain() ? 1 : isBcast() ? 4 * bcastTiles(tiles) : wgTiles(tiles);
             m_tiles = (tiles + group - 1) / group * group;
         }
 
@@ -385,6 +408,10 @@ public:
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
 
+        if (isBcast()) {
+            if constexpr (BC1) allowBcast<1>();
+            if constexpr (BC2) allowBcast<2>();
+        }
         if (ldsFits<1>()) {            // (a chain engine launches wavenet_wg as its fallback)
             allowLds<1>();
             if (!isChain()) {
@@ -655,6 +682,14 @@ public:
                      CC::ldsBytes());
             return;
         }
+        if (isBcast() && !m_condRaw) {
+            const int btw = bcastTilesFor(tiles, dump);
+            const int emb = bcastEmb(btw, dump);
+            snprintf(buf, n, "wn::wavenet_bcast<%s,%d,%d,%d,BTW=%d,EMBLDS=%d,DUMP=%d> tiles/wave=%d wgs=%d lds=%zu", F16 ? "fp16" : "fp32", R, S,
+                     A, btw, emb, dump ? 1 : 0, btw, (tiles + 4 * btw - 1) / (4 * btw),
+                     btw == 2 ? bcastLdsAny<2>(dump, emb) : bcastLdsAny<1>(dump, emb));
+            return;
+        }
         const int bt = wgTiles(tiles);
         int nEmb = bt == 2 ? embTables<2>() : embTables<1>();
         size_t lds = bt == 2 ? ldsNeed<2>(m_numLayers, nEmb) : ldsNeed<1>(m_numLayers, nEmb);
@@ -818,7 +853,7 @@ public:
         if (p.count <= 0) return true;
 
         const int tiles = (batch_size + 15) / 16;
-        bool result = isChain() ? launchChain(p, tiles, stream) : launchWg(p, tiles, stream);
+        bool result = isChain() ? launchChain(p, tiles, stream) : (isBcast() && !m_condRaw) ? launchBcast(p, tiles, stream) : launchWg(p, tiles, stream);
         if (m_pcmUser != NULL) {
             // the indices of a finished sample are final: the expansion is a per-element map of yOut
             hipLaunchKernelGGL(wn::mulaw_pcm_kernel, dim3(gridFor((size_t)batch_size * p.count)), dim3(256), 0, stream,
@@ -862,6 +897,58 @@ protected:
         gpuErrChk(hipDeviceSynchronize());
         gpuErrChk(hipMemcpy(&s, m_chainStatus + i, sizeof(unsigned), hipMemcpyDeviceToHost));
         return s;
+    }
+    // wavenet_bcast: one or two tiles per wave by batch size; the current tap's embedding table in LDS when there is room
+    template <int BTW> size_t bcastLdsAny(bool dump, int emb) const {
+        if constexpr (BTW == 1 ? BC1 : BC2) return bcastLds<BTW>(m_numLayers, dump, emb);
+        return 0;
+    }
+    int bcastEmb(int btw, bool dump) const {
+        const size_t need = btw == 2 ? bcastLdsAny<2>(dump, 1) : bcastLdsAny<1>(dump, 1);
+        return need <= kLdsMax ? 1 : 0;
+    }
+    template <int BTW, bool EMB, bool DUMP> void allowBcastK() {
+        const size_t need = bcastLds<BTW>(m_numLayers, DUMP, EMB ? 1 : 0);
+        if (need <= kLdsMax)
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_bcast<F16, R, S, A, BTW, EMB, DUMP>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    }
+    template <int BTW> void allowBcast() {
+        if constexpr (BTW == 1) {       // (launches that dump activations always run one tile per wave)
+            allowBcastK<BTW, false, true>();
+            allowBcastK<BTW, true, true>();
+        }
+        if constexpr (F16) {
+            allowBcastK<BTW, false, false>();
+            allowBcastK<BTW, true, false>();
+        }
+    }
+    template <int BTW, bool EMB, bool DUMP> bool launchBcastK(wn::Params& p, int tiles, hipStream_t stream) {
+        using BB = wn::BCfg<F16, R, S, A, BTW>;
+        const int grid = (tiles + BB::TILES_WG - 1) / BB::TILES_WG;
+        hipLaunchKernelGGL((wn::wavenet_bcast<F16, R, S, A, BTW, EMB, DUMP>), dim3(grid), dim3(BB::THREADS),
+                           bcastLds<BTW>(m_numLayers, DUMP, EMB ? 1 : 0), stream, p);
+        return hipGetLastError() == hipSuccess;
+    }
+    template <int BTW> bool launchBcastB(wn::Params& p, int tiles, hipStream_t stream) {
+        bool dump = true;
+        if constexpr (F16) dump = p.dump != 0;
+        const bool emb = bcastEmb(BTW, dump) != 0;
+        if constexpr (F16) {
+            if (!dump) return emb ? launchBcastK<BTW, true, false>(p, tiles, stream) : launchBcastK<BTW, false, false>(p, tiles, stream);
+        }
+        if constexpr (BTW == 1) return emb ? launchBcastK<BTW, true, true>(p, tiles, stream) : launchBcastK<BTW, false, true>(p, tiles, stream);
+        return false;
+    }
+    // (a launch that dumps activations runs one tile per wave whatever the batch: the two-tile kernel has no registers for the dump;
+    //  ring, conditioning and history are laid out per tile, so the launches of one engine may mix the two)
+    int bcastTilesFor(int tiles, bool dump) const { return dump ? 1 : bcastTiles(tiles); }
+    bool launchBcast(wn::Params& p, int tiles, hipStream_t stream) {
+        if constexpr (BC2) {
+            if (bcastTilesFor(tiles, p.dump != 0) == 2) return launchBcastB<2>(p, tiles, stream);
+        }
+        if constexpr (BC1) return launchBcastB<1>(p, tiles, stream);
+        return false;
     }
     // wavenet_wg by batch size: one, two or three tiles per workgroup
     bool launchWg(wn::Params& p, int tiles, hipStream_t stream) {

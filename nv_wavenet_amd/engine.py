@@ -30,7 +30,10 @@ class Org:
     WG3 = 4         # three tiles per workgroup (fp16, R <= 64; else two)
     CHAIN = 5       # wn::wavenet_chain: multi-CU, weights resident, fewest CUs
     CHAIN1 = 6      # wn::wavenet_chain, one layer per CU
-    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6}
+    BCAST = 7       # wn::wavenet_bcast: whole tiles per wave, weights broadcast through an LDS ring; 1 or 2 tiles per wave by batch
+    BCAST1 = 8
+    BCAST2 = 9
+    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6, "bcast": 7, "bcast1": 8, "bcast2": 9}
 
 
 def supported_configs():
@@ -62,8 +65,8 @@ class WavenetEngine:
         self.precision = precision
         if isinstance(organisation, str) or organisation is None:
             organisation = Org.BY_NAME[organisation]
-        if organisation not in range(7):
-            raise ValueError("organisation must be 0..6")
+        if organisation not in range(10):
+            raise ValueError("organisation must be 0..9")
         self._h = lib.nvw_create_ex(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
                                     1 if tanhEmbed else 0, organisation)
         if not self._h:
