@@ -120,30 +120,22 @@ struct BCfg {
 #define WN_BC_R10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
 #define WN_BC_RES                                                                                                                   \
     WN_BC_R10(16), WN_BC_R10(17), WN_BC_R10(18), WN_BC_R10(19), WN_BC_R10(20), WN_BC_R10(21), WN_BC_R10(22), WN_BC_R10(23), WN_BC_R10(24), \
-        "a250", "a251", "a252", "a253", "a254", "a255"
-constexpr int kBcCdReg = 160, kBcXpReg = 224;
+        "a250", "a251", "a252", "a253", "a254", "a255", "a159"
+constexpr int kBcCdReg = 160, kBcXpReg = 224;       // (a159: where the dummy loads below put their word)
 __host__ __device__ constexpr int bc_cd_reg(int set, int i) { return kBcCdReg + 32 * set + 4 * i; }
 __host__ __device__ constexpr int bc_xp_reg(int set, int i) { return kBcXpReg + 16 * set + 4 * i; }
 
-// CH consecutive 1-KiB pieces of the wave's stream -> LDS at m0 = ldsDst (+ offset field); soff = byte position in the stream
-template <int CH> WN_DEV void bc_dma(unsigned ldsDst, unsigned lane16, rsrc_t rs, unsigned soff) {
-    static_assert(CH >= 1 && CH <= 4, "chunk vs the 12-bit offset field");
-    if constexpr (CH == 1)
-        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldsDst), "v"(lane16), "s"(rs), "s"(soff) : "memory", WN_BC_RES);
-    if constexpr (CH == 2)
-        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" ::"s"(ldsDst),
-                     "v"(lane16), "s"(rs), "s"(soff)
-                     : "memory", WN_BC_RES);
-    if constexpr (CH == 3)
-        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds\n\t"
-                     "buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" ::"s"(ldsDst),
-                     "v"(lane16), "s"(rs), "s"(soff)
-                     : "memory", WN_BC_RES);
-    if constexpr (CH == 4)
-        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds\n\t"
-                     "buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds" ::"s"(ldsDst),
-                     "v"(lane16), "s"(rs), "s"(soff)
-                     : "memory", WN_BC_RES);
+// CH consecutive 1-KiB pieces of the wave's stream (at src, wave-uniform) -> LDS at ldsDst: lane l's 16 bytes land at M0 + 16 l, and M0
+// reaches the whole 160 KiB (scripts/ubench/ldsdma_addr.hip; the instruction's offset field would move source AND destination).
+WN_DEV void bc_dma1(unsigned ldsDst, unsigned voff, const char* src) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsDst), "v"(voff), "s"(src) : "memory", WN_BC_RES);
+}
+template <int CH> WN_DEV void bc_dma(unsigned ldsDst, unsigned lane16, const char* src) {
+    static_assert(CH >= 1 && CH <= 4, "pieces per chunk");
+    bc_dma1(ldsDst, lane16, src);
+    if constexpr (CH > 1) bc_dma1(ldsDst + 1024u, lane16 + 1024u, src);
+    if constexpr (CH > 2) bc_dma1(ldsDst + 2048u, lane16 + 2048u, src);
+    if constexpr (CH > 3) bc_dma1(ldsDst + 3072u, lane16 + 3072u, src);
 }
 // one 16-byte-per-lane load into the fixed accumulator quad a[REG:REG+3], streaming policy; valid only behind a bc_wait_set
 template <int REG> WN_DEV void bc_load_fixed(unsigned voff, rsrc_t rs, unsigned soff) {
@@ -153,10 +145,11 @@ template <int REG> WN_DEV void bc_load_fixed(unsigned voff, rsrc_t rs, unsigned 
 WN_DEV void bc_store(floatx4 v, unsigned voff, rsrc_t rs, unsigned soff) {
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory", WN_BC_RES);
 }
-// a vector-memory operation that only keeps the count of a boundary's group (4 bytes per lane of a hot line)
+// A vector-memory operation that only keeps the count of a boundary's group (4 bytes per lane of a hot line).  Its destination
+// is one of the fixed registers too: the word arrives long after the statement, in a register the compiler would otherwise
+// have given to something else by then (the first version of this kernel computed one wrong tile per layer that way).
 WN_DEV void bc_dummy(unsigned voff, rsrc_t rs) {
-    unsigned d;
-    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(d) : "v"(voff), "s"(rs) : "memory", WN_BC_RES);
+    asm volatile("buffer_load_dword a159, %0, %1, 0 offen" ::"v"(voff), "s"(rs) : "memory", WN_BC_RES);
 }
 // Every load of register set SET has landed once at most N younger vector-memory operations are outstanding; from here on the
 // set's registers are values the compiler may use (cd[i], i < 8; xp[i], i < 4: the first BTW*NCD / BTW*KF_R are meaningful)
@@ -276,7 +269,8 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
     const size_t strmBytes = C::waveStreamFrags(L) * 1024;                 // one stream of the blob; cyclic per sample
     const unsigned totBytes = (unsigned)strmBytes;
     const char* const wbase = (const char*)p.wblob;
-    const rsrc_t rsW = make_rsrc(wbase + (size_t)w * strmBytes);            // this wave copies its own stream
+    const char* const wMine = wbase + (size_t)w * strmBytes;               // this wave copies its own stream
+    const rsrc_t rsW = make_rsrc(wMine);
     const unsigned ringMineLds =
         (unsigned)(size_t)(__attribute__((address_space(3))) char*)ringLds + (unsigned)w * (unsigned)(NSLOT * 1024);
     const size_t ringTile = (size_t)p.ringSlots * KF_R * 1024;
@@ -332,7 +326,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
     unsigned dmaOff = 0;
 #pragma unroll
     for (int c = 0; c < B::NCH; c++) {
-        bc_dma<CH>(ringMineLds + (unsigned)(c * CH * 1024), lane16, rsW, dmaOff);
+        bc_dma<CH>(ringMineLds + (unsigned)(c * CH * 1024), lane16, wMine + dmaOff);
         dmaOff += CH * 1024;
     }
     // the fragment FIFO: the NQ fragments of RAP consecutive positions, read RAP positions ahead of the MFMAs
@@ -413,7 +407,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
     // ---- boundary of a chunk: everybody's copies of the chunk after next have landed; the chunk just consumed is refilled ----
     auto boundary = [&](auto SLOT0, auto&& ops) {
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(B::kWaitBoundary) : "memory", WN_BC_RES);
-        bc_dma<CH>(ringMineLds + (unsigned)(decltype(SLOT0)::value * 1024), lane16, rsW, dmaOff);
+        bc_dma<CH>(ringMineLds + (unsigned)(decltype(SLOT0)::value * 1024), lane16, wMine + dmaOff);
         dmaOff += CH * 1024;
         if (dmaOff == totBytes) dmaOff = 0;
         ops();
