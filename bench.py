@@ -528,9 +528,16 @@ def main():
                                "multi_cu_chain": reference_definition_khz(sh, 3),
                                "auto": reference_definition_khz(sh, 0)}
         bt = 64 * ncu                                 # four tiles per CU: more workgroups than CUs, not real time
-        khz_t = sweep.get(bt) or measure_steady_khz(w, bt)[0]
-        thr = {"batch_per_gpu": bt, "khz_per_utterance": khz_t, "samples_per_sec_per_gpu": bt * khz_t * 1e3,
-               "kernel": HEADLINE_KERNELS[3], "real_time": bool(khz_t >= REALTIME_KHZ)}
+        # beyond three tiles per CU the engine switches to wn::wavenet_bcast (every wave its own tiles, weights broadcast through
+        # LDS): throughput, not real time; reported at four and at eight tiles per CU
+        thr = {"definition": "batches beyond the real-time capacity: more utterances per GPU at a lower rate per utterance "
+                             "(steady state, samples 640..1151; the engine's own choice of organisation)", "points": []}
+        for bt_ in (bt, 2 * bt):
+            khz_t, info_t = measure_steady_khz(w, bt_, 256)
+            thr["points"].append({"batch_per_gpu": bt_, "khz_per_utterance": khz_t, "samples_per_sec_per_gpu": bt_ * khz_t * 1e3,
+                                  "kernel": info_t.split(" ")[0], "real_time": bool(khz_t >= REALTIME_KHZ)})
+        best_t = max(thr["points"], key=lambda q: q["samples_per_sec_per_gpu"])
+        thr.update({k: best_t[k] for k in ("batch_per_gpu", "khz_per_utterance", "samples_per_sec_per_gpu", "kernel", "real_time")})
         e2e = {"definition": "conditioning fp32 [N][L][B][2R] in HBM, packed per chunk of 256 samples on a second stream "
                              "behind the generation of the previous chunk; Philox selectors; samples left in HBM",
                "sweep_khz": {}}

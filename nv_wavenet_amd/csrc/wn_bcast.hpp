@@ -87,7 +87,7 @@ struct BCfg {
     static constexpr int REQ_HEAD = REQ_LOADS - GROUPS_L0 * E > 0 ? REQ_LOADS - GROUPS_L0 * E : 0;
     static constexpr bool SUPPORTED =
         R == 64 && NQ == 4 && A <= 256 && S <= 256 && BTW >= 1 && BTW <= 2 && NSLOT >= 8 && NCH >= 4 && CH >= RAP && P_CUR % RAP == 0 &&
-        FLW % RAP == 0 && FHWP % RAP == 0 && (FW_ZS + C::PAD1) % RAP == 0 && REQ_HEAD <= E && REQ_GROUPS <= GROUPS_L && P_PREV % CH == 0 &&
+        FLW % RAP == 0 && FHWP % RAP == 0 && REQ_HEAD <= E && REQ_GROUPS <= GROUPS_L && P_PREV % CH == 0 &&
         P0_PREV % CH == 0 && kWaitBoundary <= 63 && kWaitUse <= 63;
     // gate tile of fragment-local slot `it` of stream q (Cfg: a wave's rows come in (tanh tile, sigmoid tile) pairs)
     __host__ __device__ static constexpr int gateTile(int q, int it) { return q + NQ * (it >> 1) + (it & 1) * RT; }
@@ -127,8 +127,12 @@ __host__ __device__ constexpr int bc_xp_reg(int set, int i) { return kBcXpReg + 
 
 // CH consecutive 1-KiB pieces of the wave's stream (at src, wave-uniform) -> LDS at ldsDst: lane l's 16 bytes land at M0 + 16 l, and M0
 // reaches the whole 160 KiB (scripts/ubench/ldsdma_addr.hip; the instruction's offset field would move source AND destination).
+// Timing experiments (results are wrong with any of them): WN_BC_ABL_NODMA no weight copies; WN_BC_ABL_NOBAR no chunk barriers /
+// waits; WN_BC_ABL_NOFIFO no fragment reads from LDS; WN_BC_ABL_NOREQ no conditioning / tap / dummy loads, no ring stores
 WN_DEV void bc_dma1(unsigned ldsDst, unsigned voff, const char* src) {
+#ifndef WN_BC_ABL_NODMA
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsDst), "v"(voff), "s"(src) : "memory", WN_BC_RES);
+#endif
 }
 template <int CH> WN_DEV void bc_dma(unsigned ldsDst, unsigned lane16, const char* src) {
     static_assert(CH >= 1 && CH <= 4, "pieces per chunk");
@@ -140,16 +144,22 @@ template <int CH> WN_DEV void bc_dma(unsigned ldsDst, unsigned lane16, const cha
 // one 16-byte-per-lane load into the fixed accumulator quad a[REG:REG+3], streaming policy; valid only behind a bc_wait_set
 template <int REG> WN_DEV void bc_load_fixed(unsigned voff, rsrc_t rs, unsigned soff) {
     static_assert(REG >= kBcCdReg && REG + 3 <= 255 && REG % 4 == 0, "fixed register map");
+#ifndef WN_BC_ABL_NOREQ
     asm volatile("buffer_load_dwordx4 a[%0:%1], %2, %3, %4 offen nt" ::"n"(REG), "n"(REG + 3), "v"(voff), "s"(rs), "s"(soff) : "memory", WN_BC_RES);
+#endif
 }
 WN_DEV void bc_store(floatx4 v, unsigned voff, rsrc_t rs, unsigned soff) {
+#ifndef WN_BC_ABL_NOREQ
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory", WN_BC_RES);
+#endif
 }
 // A vector-memory operation that only keeps the count of a boundary's group (4 bytes per lane of a hot line).  Its destination
 // is one of the fixed registers too: the word arrives long after the statement, in a register the compiler would otherwise
 // have given to something else by then (the first version of this kernel computed one wrong tile per layer that way).
 WN_DEV void bc_dummy(unsigned voff, rsrc_t rs) {
+#ifndef WN_BC_ABL_NOREQ
     asm volatile("buffer_load_dword a159, %0, %1, 0 offen" ::"v"(voff), "s"(rs) : "memory", WN_BC_RES);
+#endif
 }
 // Every load of register set SET has landed once at most N younger vector-memory operations are outstanding; from here on the
 // set's registers are values the compiler may use (cd[i], i < 8; xp[i], i < 4: the first BTW*NCD / BTW*KF_R are meaningful)
@@ -329,6 +339,9 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
         bc_dma<CH>(ringMineLds + (unsigned)(c * CH * 1024), lane16, wMine + dmaOff);
         dmaOff += CH * 1024;
     }
+    // every position consumed refills the slot CH positions back with the stream NSLOT positions on (consume): the launch's
+    // first CH positions have no finished chunk behind them -- they rewrite the last CH slots with what these hold already
+    dmaOff = (unsigned)((NSLOT - CH) * 1024);
     // the fragment FIFO: the NQ fragments of RAP consecutive positions, read RAP positions ahead of the MFMAs
     frag fifo[RAP][NQ];
     auto fifo_fill = [&](auto POS) {       // position POS (relative to a multiple of NSLOT) into its FIFO slot
@@ -336,7 +349,11 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
         // (kept in this order: the uses below start with the LAST stream's fragment, so that one counted wait covers a position)
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
+#ifndef WN_BC_ABL_NOFIFO
             fifo[pos % RAP][q] = *(const frag*)(ringLds + ((q * NSLOT + pos % NSLOT) << 10) + lane16);
+#else
+            if (pos < 2) fifo[pos % RAP][q] = *(const frag*)(ringLds + ((q * NSLOT + pos % NSLOT) << 10) + lane16);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -405,12 +422,21 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
     static_for<REQ_HEAD>([&](auto J) { req_one(SET0{}, J, condReq, (unsigned)(dS2.off + (t0 & (dS2.d - 1)))); });
 
     // ---- boundary of a chunk: everybody's copies of the chunk after next have landed; the chunk just consumed is refilled ----
-    auto boundary = [&](auto SLOT0, auto&& ops) {
+    // The chunk just consumed is NOT refilled in one go: the four waves' copies of a chunk issued together are a burst that the
+    // CU's vector-memory path takes a few hundred cycles to accept, every wave stalled on its issue (measured: 30 of 125 k cycles
+    // per sample).  Its pieces follow one per position of the next chunk's consumption (consume); the counts stay what they were:
+    // behind the last piece of a chunk come the E operations of the boundary that ends the chunk after, then whole groups.
+    auto boundary = [&](auto&& ops) {
+#ifndef WN_BC_ABL_NOBAR
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(B::kWaitBoundary) : "memory", WN_BC_RES);
-        bc_dma<CH>(ringMineLds + (unsigned)(decltype(SLOT0)::value * 1024), lane16, wMine + dmaOff);
-        dmaOff += CH * 1024;
-        if (dmaOff == totBytes) dmaOff = 0;
+#endif
         ops();
+    };
+    // piece of ring slot SLOT: the stream NSLOT positions on (dmaOff walks the stream one position per call)
+    auto dma_piece = [&](auto SLOT) {
+        bc_dma1(ringMineLds + (unsigned)(decltype(SLOT)::value * 1024), lane16, wMine + dmaOff);
+        dmaOff += 1024;
+        if (dmaOff == totBytes) dmaOff = 0;
     };
     // consume stream positions [P0, P0 + N) (relative to a multiple of FLW): use(f, a[]) gets the NQ fragments of position
     // P0 + f; grp(boundary position) supplies the E other operations of every chunk boundary inside
@@ -423,9 +449,11 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
             for (int q = 0; q < NQ; q++) a[q] = fifo[pos % RAP][q];
             use(FI, a);
             fifo_fill(std::integral_constant<int, pos + RAP>{});
+            // the slot CH positions back belongs to the chunk that everybody finished before the latest boundary
+            dma_piece(std::integral_constant<int, (pos + NSLOT - CH) % NSLOT>{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((pos + 1) % CH == 0) {
-                boundary(std::integral_constant<int, (pos + 1 - CH) % NSLOT>{}, [&]() { grp(std::integral_constant<int, pos + 1>{}); });
+                boundary([&]() { grp(std::integral_constant<int, pos + 1>{}); });
                 __builtin_amdgcn_sched_barrier(0);
             }
         });

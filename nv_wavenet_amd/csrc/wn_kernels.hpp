@@ -628,13 +628,18 @@ WN_DEV void gemm_b(WStream<F16, PF, PIN>& ws, rsrc_t rs, int pos0, int basePos, 
 #pragma unroll
             for (int m0 = 0; m0 < G; m0 += TG) {
                 typename Prec<F16>::frag a[TG];
-                take_group<F16, PF, PIN, TG>(ws, pos0 + (mg * KF + kf) * G + m0, a);
+                const int idx = pos0 + (mg * KF + kf) * G + m0;
+                take_group<F16, PF, PIN, TG>(ws, idx, a);
+                // the refill of the take BEFORE this one sits between this take's pin and its first MFMA: the slot it writes was
+                // read by MFMAs already issued, and the instruction fills the wait state the pinned operand needs in front of an
+                // MFMA (an s_nop otherwise, 18 a layer; round 4: -1.8 % on one workgroup, -0.5 % at 12 288 utterances)
+                if (!(mg == 0 && kf == 0 && m0 == 0)) refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, idx - TG, basePos, wrapPos, laneOff);
 #pragma unroll
                 for (int mi = 0; mi < TG; mi++)
 #pragma unroll
                     for (int bt = 0; bt < BT; bt++)
                         acc[bt][mg * G + m0 + mi] = mma(a[mi], b[bt][kf], acc[bt][mg * G + m0 + mi]);
-                refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, pos0 + (mg * KF + kf) * G + m0, basePos, wrapPos, laneOff);
+                if (mg == MT / G - 1 && kf == KF - 1 && m0 + TG >= G) refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, idx, basePos, wrapPos, laneOff);
             }
         }
     }
@@ -1287,6 +1292,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         constexpr int kf = (q / G0) % KF_R, mg = q / (G0 * KF_R), mi0 = q % G0;
                         frag a[G];
                         take_group<F16, PF, ws_pin, G>(ws, C::P_SKIP + gi * G, a);
+                        if constexpr (gi > 0) refill_group<F16, PF, 0, ws_pin, G>(ws, rsW, C::P_SKIP + (gi - 1) * G, wl, 0, laneOff);   // (see gemm_b)
                         static_for<G * BT>([&](auto MI) {
                             constexpr int mi = decltype(MI)::value / BT, bt = decltype(MI)::value % BT;
                             constexpr int mt = mg * G0 + mi0 + mi, m = (q + mi) * BT + bt;
@@ -1294,7 +1300,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                             __builtin_amdgcn_sched_barrier(0);
                             static_for_range<m * NS / NM, (m + 1) * NS / NM>(stage);
                         });
-                        refill_group<F16, PF, 0, ws_pin, G>(ws, rsW, C::P_SKIP + gi * G, wl, 0, laneOff);
+                        if constexpr (gi == STW * KF_R / G - 1) refill_group<F16, PF, 0, ws_pin, G>(ws, rsW, C::P_SKIP + gi * G, wl, 0, laneOff);
                         // Dilated tap and conditioning of layer l+2 (HBM) into the register set this layer has finished
                         // with, three quarters into the skip GEMM.  VMEM returns in order per wave: the weight fragments
                         // requested behind these loads wait for them, and the first of those is taken PF takes later --
@@ -1409,13 +1415,20 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         };
         {
             // schedule entries of layers l, l+1, l+2 (the latter two may be layers 0, 1 of the next sample: table entries L, L+1)
-            layer(std::false_type{}, 0, p.dil[0], p.dil[1], p.dil[2], xpA, cdA, xpB, cdB);
+            // the three schedule entries travel with the loop (scalar arithmetic: the scalar LOADS of the table in the kernel arguments
+            // return out of order, so every LDS wait near one became an lgkmcnt(0); round 4)
+            Dil da = dil_first(), db = dil_next(da, p.maxDilation, L == 1), dc = dil_next(db, p.maxDilation, L == 2);
+            auto adv = [&](int l) { da = db; db = dc; dc = dil_next(dc, p.maxDilation, l + 3 == L); };
+            layer(std::false_type{}, 0, da, db, dc, xpA, cdA, xpB, cdB);
+            adv(0);
             int l = 1;
             for (; l + 1 < L; l += 2) {
-                layer(std::true_type{}, l, p.dil[l], p.dil[l + 1], p.dil[l + 2], xpB, cdB, xpA, cdA);
-                layer(std::true_type{}, l + 1, p.dil[l + 1], p.dil[l + 2], p.dil[l + 3], xpA, cdA, xpB, cdB);
+                layer(std::true_type{}, l, da, db, dc, xpB, cdB, xpA, cdA);
+                adv(l);
+                layer(std::true_type{}, l + 1, da, db, dc, xpA, cdA, xpB, cdB);
+                adv(l + 1);
             }
-            if (l < L) layer(std::true_type{}, l, p.dil[l], p.dil[l + 1], p.dil[l + 2], xpB, cdB, xpA, cdA);
+            if (l < L) layer(std::true_type{}, l, da, db, dc, xpB, cdB, xpA, cdA);
             if (L & 1) {
                 // odd layer count: layer 0 of the next sample was prefetched into the odd set
 #pragma unroll

@@ -111,6 +111,8 @@ if "time" in what:
     w = bench.make_weights()
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     pts = [("wg3", 4, 48 * ncu), ("bcast1", 8, 64 * ncu), ("bcast2", 9, 128 * ncu), ("bcast1", 8, 64), ("bcast2", 9, 128)]
+    if os.environ.get("R4_POINTS"):       # e.g. "bcast1:8:64,bcast2:9:128"
+        pts = [(a, int(b), int(c)) for a, b, c in (x.split(":") for x in os.environ["R4_POINTS"].split(","))]
     for name, org, B in pts:
         t0 = time.time()
         e, N, keep = bench.steady_engine(w, B, 128, organisation=org)

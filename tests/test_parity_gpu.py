@@ -21,10 +21,18 @@ def _bspb(B):
 # the kernel organisations: wavenet_wg with one / two / three tiles of 16 utterances per workgroup (wn_kernels.hpp; the engine
 # picks by batch size: beyond one / two tiles per CU) and the multi-CU chain with resident weights (wn_chain.hpp; "chain": as
 # many layers per CU as stay resident, "chain1": one layer per CU)
-MODES = ["wg", "wg2", "chain"]
+# ... and wn::wavenet_bcast (wn_bcast.hpp, round 4): every wave runs the whole network for its own tiles, the weights broadcast
+# through an LDS ring ("bcast": one tile per wave, "bcast2": two -- fp16, launches without the activation dump)
+MODES = ["wg", "wg2", "chain", "bcast"]
 ALL_MODES = MODES + ["chain1"]
-FP16_MODES = ["wg", "wg2", "wg3", "chain", "chain1"]
-KERNEL_OF = {"wg": "wavenet_wg<", "wg2": "wavenet_wg<", "wg3": "wavenet_wg<", "chain": "wavenet_chain<", "chain1": "wavenet_chain<"}
+FP16_MODES = ["wg", "wg2", "wg3", "chain", "chain1", "bcast", "bcast2"]
+KERNEL_OF = {"wg": "wavenet_wg<", "wg2": "wavenet_wg<", "wg3": "wavenet_wg<", "chain": "wavenet_chain<", "chain1": "wavenet_chain<",
+             "bcast": "wavenet_bcast<", "bcast2": "wavenet_bcast<"}
+
+
+def _bcast_shape(shape):
+    """shapes wn::wavenet_bcast exists for (BCfg::SUPPORTED + the engine's depth check); others run wavenet_wg"""
+    return shape.R == 64 and shape.S <= 256 and shape.A <= 256 and shape.L >= 3
 
 
 def _check_mode(e, mode, shape, precision=32):
@@ -34,6 +42,11 @@ def _check_mode(e, mode, shape, precision=32):
     if mode in ("chain", "chain1") and shape.R >= 256:
         assert "wavenet_wg<" in info, info
         return
+    if mode in ("bcast", "bcast2") and not _bcast_shape(shape):
+        assert "wavenet_wg<" in info, info
+        return
+    if mode == "bcast2" and precision == 16:
+        assert "BTW=2" in info, info
     assert KERNEL_OF[mode] in info, (mode, info)
     if mode == "wg2" and shape.R < 128:   # (two tiles of R >= 128 do not fit the LDS of one workgroup: one tile runs)
         assert "BT=2" in info, info
@@ -224,7 +237,7 @@ def test_fp16_engine_against_the_oracle_o1(name, mode, record_property):
 @pytest.mark.parametrize("name", ["C2", "C3", "C4"])
 def test_fp16_organisations_are_bit_identical_o1(name):
     """Same arithmetic in the same order in every organisation: the free-running fp16 samples are IDENTICAL."""
-    ys = {m: _fp16_checked_run(name, m)[1] for m in (["wg", "chain"] if name == "C4" else ["wg", "wg3", "chain"])}
+    ys = {m: _fp16_checked_run(name, m)[1] for m in (["wg", "chain"] if name == "C4" else ["wg", "wg3", "chain", "bcast", "bcast2"])}
     first = ys.pop("wg")
     for m, y in ys.items():
         assert np.array_equal(first, y), "wavenet_wg and %s disagree in fp16" % m
@@ -425,7 +438,8 @@ def test_conditioning_consumed_in_place(mode, precision):
     e.close()
 
 
-@pytest.mark.parametrize("mode,precision", [("wg", 32), ("chain", 32), ("wg", 16), ("wg2", 16), ("wg3", 16), ("chain", 16)])
+@pytest.mark.parametrize("mode,precision", [("wg", 32), ("chain", 32), ("bcast", 32), ("wg", 16), ("wg2", 16), ("wg3", 16), ("chain", 16),
+                                            ("bcast", 16), ("bcast2", 16)])
 def test_conditioning_produced_in_fragment_order(mode, precision):
     """Round 3: conditioning the caller PRODUCES in the engine's fragment order (setConditioningPacked; a model folds the
     channel permutation and the gate's pre-scale into its conditioning convolution, nv_wavenet.py: get_cond_input(layout=
@@ -535,6 +549,91 @@ def test_benchmarked_launch_is_the_parity_tested_one(tiles_per_cu):
     bad = np.argwhere((y != ref).any(axis=1))
     assert bad.size == 0, "utterance %d of the benchmarked launch differs from the 16-utterance run" % int(bad[0, 0])
     e.close()
+
+
+@pytest.mark.parametrize("tiles_per_cu", [0, 3])
+def test_benchmarked_path_exactly(tiles_per_cu):
+    """the launch sequence bench.py times (bench.py: steady_engine + step) reproduced to the letter -- fp16, O(1)
+    weights, in-kernel Philox selectors (setSelectorSeed), conditioning packed chunk-wise from one reused 64-sample block
+    (packConditioning), run_range(0, 640) and then run_range(640, n): what is compared is nv_wavenet_test.cu:259-304's,
+    what the selectors replace is wavenet_infer.cu:92-94's rand() table.  tiles_per_cu = 0: 16 utterances, held to the fp32
+    oracle fed philox_selectors(seed) and the same conditioning by util.fp16_bars (the last launch with the dump on; the
+    dump-free kernels must generate the same samples); tiles_per_cu = 3: the headline batch (3 x 16 x CUs utterances, the
+    three-tile kernel bench.py asserts), every utterance bit-identical to its 16-utterance original."""
+    import torch
+    import bench
+    from nv_wavenet_amd import WavenetEngine
+    n_timed, seed = 64, 111
+    N = bench.STEADY_FROM + n_timed
+    case = cases.Case("C3_fp16_benchmarked_path", 30, [], cases.Shape(64, 256, 256, 20, 16, N, 512), 3, 1, 128)
+    s = case.shape
+    t = util.gen_o1(case, half=True)
+    block = np.ascontiguousarray(t.Lh[:bench.COND_BLOCK])                  # [64][L][16][2R]: the reused block
+    t.Lh = np.ascontiguousarray(np.tile(block, (N // bench.COND_BLOCK, 1, 1, 1)))
+    t.sel = util.O.philox_selectors(seed, N, s.B)
+    assert t.Lh.shape[0] == N
+
+    def engine(B, org):
+        e = WavenetEngine(s.R, s.S, s.A, s.L, s.maxD, B, N, impl=0, tanhEmbed=True, precision=16, organisation=org)
+        e.setEmbeddings(t.embP, t.embC)
+        for l in range(s.L):
+            e.setLayerWeights(l, t.Wprev[l], t.Wcur[l], t.Bh[l], t.Wres[l], t.Bres[l], t.Wskip[l], t.Bskip[l])
+        e.setOutWeights(t.Wzs, t.Bzs, t.Wza, t.Bza)
+        idx = torch.arange(B, device="cuda") % s.B
+        blk = torch.from_numpy(block).cuda()[:, :, idx, :].contiguous()
+        e.setSelectorSeed(seed)
+        e.resetHistory()
+        for first in range(0, N, bench.COND_BLOCK):                        # exactly bench.py: steady_engine
+            e.packConditioning(blk, first, bench.COND_BLOCK)
+        torch.cuda.synchronize()
+        return e, idx.cpu().numpy()
+
+    def sequence(B, org, check=None):
+        e, idx = engine(B, org)
+        if check:
+            assert e.kernelInfo(B, False).split(" ")[0] == check, e.kernelInfo(B, False)
+        assert e.run_partial_chunk(0, bench.STEADY_FROM, N, B)
+        assert e.run_partial_chunk(bench.STEADY_FROM, n_timed, N, B)
+        e.synchronize()
+        y = torch.full((B, N), -1, dtype=torch.int32, device="cuda")
+        e.getYOut(y, 0, N)
+        e.synchronize()
+        e.close()
+        return y.cpu().numpy()
+
+    if tiles_per_cu == 0:
+        # 16 utterances, production kernels for the whole sequence ...
+        y16 = sequence(s.B, util.MODE_ORG["wg"])
+        # ... and once more with the dump on in the last launch: held to the oracle
+        e, _ = engine(s.B, util.MODE_ORG["wg"])
+        assert e.run_partial_chunk(0, bench.STEADY_FROM, N, s.B)
+        yd = np.full((s.B, N), -1, dtype=np.int32)
+        assert e.run_partial(bench.STEADY_FROM, N, s.B, yd, 1, True)
+        e.synchronize()
+        got = util.engine_getters(e, s.L)
+        got["y"] = yd
+        e.close()
+        assert np.array_equal(yd, y16), "dump and dump-free kernels disagree on the benchmarked sequence"
+        st = util.fp16_bars(_teacher_forced_ref(case, t, yd), got, t.sel.T, "benchmarked path, 16 utterances")
+        print("benchmarked path, 16 utterances:", {k: round(v, 4) for k, v in st.items()})
+        # Philox selectors are a function of (sample, utterance NUMBER): utterance 16 k + j shares j's conditioning but draws its
+        # own selectors.  48 utterances on the one-tile kernel (whose first 16 are the oracle-held ones above) pin the three-tile
+        # kernel itself and the throughput organisation, selectors of utterances >= 16 included
+        y48 = sequence(3 * s.B, util.MODE_ORG["wg"])
+        assert np.array_equal(y48[:s.B], y16)
+        assert not np.array_equal(y48[s.B:2 * s.B], y16), "utterances 16.. drew utterance 0..'s selectors"
+        for mode in ("wg3", "bcast", "bcast2"):
+            assert np.array_equal(sequence(3 * s.B, util.MODE_ORG[mode]), y48), "%s differs from the one-tile kernel on the benchmarked sequence" % mode
+        return
+    # the headline batch (the engine's own choice: three tiles per workgroup, the kernel bench.py asserts): its first 1024
+    # utterances against the one-tile kernel run on 1024 utterances, whose first 16 are the oracle-held ones of the other case
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    B = tiles_per_cu * 16 * ncu
+    y = sequence(B, 0, bench.HEADLINE_KERNELS[tiles_per_cu])
+    y1k = sequence(1024, util.MODE_ORG["wg"])
+    assert np.array_equal(y[:1024], y1k), "the headline batch differs from the one-tile kernel on the benchmarked sequence"
+    assert np.array_equal(y1k[:s.B], sequence(s.B, util.MODE_ORG["wg"]))
+    assert all(len(np.unique(y[b])) > 8 for b in range(0, B, 997))
 
 
 def _wrapper_model(R, S, A, L, B, N, seed=7):
@@ -851,7 +950,7 @@ def test_full_chip_batches_by_replication(B):
     e.close()
 
 
-@pytest.mark.parametrize("B", [4112, 8208, 12304, 16400])
+@pytest.mark.parametrize("B", [4112, 8208, 12304, 16368, 16400])
 def test_full_chip_batches_by_replication_fp16(B):
     """The same property for the fp16 production path (dump-free kernels, engine's own choice of organisation at
     full-chip batch sizes; O(1) inputs): the big batch must repeat, bit for bit, what the one-tile kernel generates for
@@ -874,8 +973,9 @@ def test_full_chip_batches_by_replication_fp16(B):
     tiles = (B + 15) // 16
     info = e.kernelInfo(B, False)
     assert "DUMP=0" in info and "fp16" in info, info
-    want = "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
-    assert want in info, (info, ncu)
+    # ... and beyond three tiles per CU the throughput organisation, wn::wavenet_bcast (two tiles per wave beyond four per CU)
+    want = "BTW=2" if tiles > 4 * ncu else "BTW=1" if tiles > 3 * ncu else "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
+    assert want in info and ("wavenet_bcast<" in info) == (tiles > 3 * ncu), (info, ncu)
     y = np.full((B, s.N), -1, dtype=np.int32)
     assert e.run(s.N, B, y, 1, False)
     e.synchronize()
