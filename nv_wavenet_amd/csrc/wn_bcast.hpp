@@ -74,15 +74,24 @@ struct BCfg {
     static constexpr int REQ_GROUPS = (REQ_LOADS + E - 1) / E;
     // boundaries (= groups) inside the part of a generic layer / of layer 0
     static constexpr int GROUPS_L = FLW / CH, GROUPS_L0 = P0_END / CH;
-    // before barrier k: own copies of chunk k+2 landed.  They were issued right behind barrier k+2-NCH; younger than them:
-    // the E other operations of their own group and NCH-3 whole groups
-    static constexpr int kWaitBoundary = (NCH - 3) * (CH + E) + E;
+    // before barrier k: own copies of chunk k+2 landed.  Its pieces were issued one per position while chunk k+2-NCH+1 was
+    // consumed (consume); behind the last of them: the E operations of the boundary that ended that chunk, NCH-4 whole chunks
+    // (CH pieces + E operations each) and the CH pieces of chunk k itself
+#ifndef WN_BC_WAITB
+    static constexpr int kWaitBoundary = (NCH - 3) * (CH + E);
+#else
+    static constexpr int kWaitBoundary = WN_BC_WAITB;      // (experiment: a stricter wait)
+#endif
     // conditioning / taps of layer l+2 are used behind the boundary in front of the tap GEMM at the end of layer l+1.  A
     // request issued by a generic layer fills the first REQ_GROUPS groups of the layer; the one issued by layer 0 ends in the
     // last group of layer 0's part: the youngest load of a request is followed by at least the groups of layer l+1 up to
     // that boundary
     static constexpr int USE_GROUPS = P_PREV / CH - P_CUR / CH;          // boundaries of a generic layer's part in front of its tap GEMM
+#ifndef WN_BC_WAITU
     static constexpr int kWaitUse = USE_GROUPS * (CH + E);
+#else
+    static constexpr int kWaitUse = WN_BC_WAITU;
+#endif
     // loads of layer 0's request that its own groups cannot hold: issued by the last boundary of the previous sample's head
     static constexpr int REQ_HEAD = REQ_LOADS - GROUPS_L0 * E > 0 ? REQ_LOADS - GROUPS_L0 * E : 0;
     static constexpr bool SUPPORTED =
@@ -93,8 +102,13 @@ struct BCfg {
     __host__ __device__ static constexpr int gateTile(int q, int it) { return q + NQ * (it >> 1) + (it & 1) * RT; }
     // ---- LDS layout (bytes) -------------------------------------------------------------------------------------------
     static constexpr int RING_BYTES = NQ * NSLOT * 1024;
-    static constexpr int SM_U = 8;                          // utterances per softmax pass of a wave (half a tile)
-    static constexpr int LPU = 64 / SM_U, RPL = A / LPU;    // softmax lanes per utterance, logits per lane
+    // softmax: the lane split of wavenet_wg (LPU lanes per utterance, RPL logits per lane) -- sums of the same terms in
+    // another order differ in the last bit, and a draw within that of a CDF edge would pick the neighbouring bin (measured with
+    // 8 x 32 instead of 16 x 16: 31 of 4096 utterances parted from wavenet_wg's within 704 samples).  A wave takes a tile in
+    // 16 / SM_U passes of SM_U utterances
+    static constexpr int LPU = C::LPU, RPL = C::RPL;
+    static constexpr int SM_U = 64 / LPU, SM_PASSES = 16 / SM_U;
+    static_assert(LPU <= 64 && 64 % LPU == 0 && 16 % SM_U == 0, "softmax passes of a wave");
     static constexpr int LROW = A + 4;
     static constexpr int LG_BYTES = NQ * SM_U * LROW * 4;
     static constexpr int YB_BYTES = NQ * BTW * 16 * 4;
@@ -493,15 +507,25 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
     for (int t = t0; t < tEnd; t++) {
         const bool dumpNow = DUMP && p.dump && (t == tEnd - 1);
         // selectors of the utterances this lane serves in the softmax passes: pass (b, hh) -> utterance (tileW+b)*16 + hh*SM_U + su
-        float selv[BTW][2];
+        // (drawn in-kernel: lane q < SM_PASSES of an utterance's 16-lane row draws pass q's and the row takes it over with a row
+        //  broadcast, one Philox evaluation per tile -- wavenet_wg's way of sharing the draw across its tiles)
+        float selv[BTW][B::SM_PASSES];
 #pragma unroll
-        for (int b = 0; b < BTW; b++)
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                int sb = (tileW + b) * 16 + hh * B::SM_U + su;
+        for (int b = 0; b < BTW; b++) {
+            if (p.useRng && B::LPU == 16) {
+                int sb = (tileW + b) * 16 + (sq < B::SM_PASSES ? sq : 0) * B::SM_U + su;
                 sb = sb < p.batch ? sb : p.batch - 1;
-                selv[b][hh] = p.useRng ? philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)sb) : p.sel[(size_t)t * p.maxBatch + sb];
+                const float mine = philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)sb);
+                static_for<B::SM_PASSES>([&](auto HH) { selv[b][decltype(HH)::value] = dpp_f<0x150 + decltype(HH)::value>(mine); });
+            } else {
+#pragma unroll
+                for (int hh = 0; hh < B::SM_PASSES; hh++) {
+                    int sb = (tileW + b) * 16 + hh * B::SM_U + su;
+                    sb = sb < p.batch ? sb : p.batch - 1;
+                    selv[b][hh] = p.useRng ? philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)sb) : p.sel[(size_t)t * p.maxBatch + sb];
+                }
             }
+        }
 
         // ---- embedding (nv_wavenet_reference.cpp:42-56) ------------------------------------------------------------------
         floatx4 x[BTW][RT];
@@ -809,10 +833,10 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
                 for (int i = 0; i < AT; i++) *(floatx4*)(p.za + (size_t)ub[b] * A + i * 16 + g * 4) = za[b][i];
             }
 #pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                if ((j >> 3) == hh) {
+            for (int hh = 0; hh < B::SM_PASSES; hh++) {
+                if (j / B::SM_U == hh) {
 #pragma unroll
-                    for (int i = 0; i < AT; i++) *(floatx4*)(lgMine + (j & 7) * B::LROW + i * 16 + g * 4) = za[b][i];
+                    for (int i = 0; i < AT; i++) *(floatx4*)(lgMine + (j % B::SM_U) * B::LROW + i * 16 + g * 4) = za[b][i];
                 }
                 float e[B::RPL];
                 float total;

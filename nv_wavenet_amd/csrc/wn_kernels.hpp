@@ -633,13 +633,15 @@ WN_DEV void gemm_b(WStream<F16, PF, PIN>& ws, rsrc_t rs, int pos0, int basePos, 
                 // the refill of the take BEFORE this one sits between this take's pin and its first MFMA: the slot it writes was
                 // read by MFMAs already issued, and the instruction fills the wait state the pinned operand needs in front of an
                 // MFMA (an s_nop otherwise, 18 a layer; round 4: -1.8 % on one workgroup, -0.5 % at 12 288 utterances)
-                if (!(mg == 0 && kf == 0 && m0 == 0)) refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, idx - TG, basePos, wrapPos, laneOff);
+                // (needs a ring deeper than a take: the slot being refilled must not be the one just taken)
+                constexpr bool EARLY = PF > TG;
+                if (EARLY && !(mg == 0 && kf == 0 && m0 == 0)) refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, idx - TG, basePos, wrapPos, laneOff);
 #pragma unroll
                 for (int mi = 0; mi < TG; mi++)
 #pragma unroll
                     for (int bt = 0; bt < BT; bt++)
                         acc[bt][mg * G + m0 + mi] = mma(a[mi], b[bt][kf], acc[bt][mg * G + m0 + mi]);
-                if (mg == MT / G - 1 && kf == KF - 1 && m0 + TG >= G) refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, idx, basePos, wrapPos, laneOff);
+                if (!EARLY || (mg == MT / G - 1 && kf == KF - 1 && m0 + TG >= G)) refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, idx, basePos, wrapPos, laneOff);
             }
         }
     }
@@ -1292,7 +1294,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         constexpr int kf = (q / G0) % KF_R, mg = q / (G0 * KF_R), mi0 = q % G0;
                         frag a[G];
                         take_group<F16, PF, ws_pin, G>(ws, C::P_SKIP + gi * G, a);
-                        if constexpr (gi > 0) refill_group<F16, PF, 0, ws_pin, G>(ws, rsW, C::P_SKIP + (gi - 1) * G, wl, 0, laneOff);   // (see gemm_b)
+                        constexpr bool EARLY = PF > G;      // (see gemm_b)
+                        if constexpr (EARLY && gi > 0) refill_group<F16, PF, 0, ws_pin, G>(ws, rsW, C::P_SKIP + (gi - 1) * G, wl, 0, laneOff);
                         static_for<G * BT>([&](auto MI) {
                             constexpr int mi = decltype(MI)::value / BT, bt = decltype(MI)::value % BT;
                             constexpr int mt = mg * G0 + mi0 + mi, m = (q + mi) * BT + bt;
@@ -1300,7 +1303,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                             __builtin_amdgcn_sched_barrier(0);
                             static_for_range<m * NS / NM, (m + 1) * NS / NM>(stage);
                         });
-                        if constexpr (gi == STW * KF_R / G - 1) refill_group<F16, PF, 0, ws_pin, G>(ws, rsW, C::P_SKIP + gi * G, wl, 0, laneOff);
+                        if constexpr (!EARLY || gi == STW * KF_R / G - 1) refill_group<F16, PF, 0, ws_pin, G>(ws, rsW, C::P_SKIP + gi * G, wl, 0, laneOff);
                         // Dilated tap and conditioning of layer l+2 (HBM) into the register set this layer has finished
                         // with, three quarters into the skip GEMM.  VMEM returns in order per wave: the weight fragments
                         // requested behind these loads wait for them, and the first of those is taken PF takes later --

@@ -30,9 +30,10 @@ KERNEL_OF = {"wg": "wavenet_wg<", "wg2": "wavenet_wg<", "wg3": "wavenet_wg<", "c
              "bcast": "wavenet_bcast<", "bcast2": "wavenet_bcast<"}
 
 
-def _bcast_shape(shape):
-    """shapes wn::wavenet_bcast exists for (BCfg::SUPPORTED + the engine's depth check); others run wavenet_wg"""
-    return shape.R == 64 and shape.S <= 256 and shape.A <= 256 and shape.L >= 3
+def _bcast_shape(shape, precision=16):
+    """shapes wn::wavenet_bcast exists for (BCfg::SUPPORTED + the engine's depth check); others run wavenet_wg.  (fp32, S = 128:
+    layer and head parts of the stream share no ring length of at least 8 positions.)"""
+    return shape.R == 64 and shape.A <= 256 and shape.L >= 3 and (shape.S == 256 or (shape.S == 128 and precision == 16))
 
 
 def _check_mode(e, mode, shape, precision=32):
@@ -42,7 +43,7 @@ def _check_mode(e, mode, shape, precision=32):
     if mode in ("chain", "chain1") and shape.R >= 256:
         assert "wavenet_wg<" in info, info
         return
-    if mode in ("bcast", "bcast2") and not _bcast_shape(shape):
+    if mode in ("bcast", "bcast2") and not _bcast_shape(shape, precision):
         assert "wavenet_wg<" in info, info
         return
     if mode == "bcast2" and precision == 16:
@@ -551,7 +552,7 @@ def test_benchmarked_launch_is_the_parity_tested_one(tiles_per_cu):
     e.close()
 
 
-@pytest.mark.parametrize("tiles_per_cu", [0, 3])
+@pytest.mark.parametrize("tiles_per_cu", [0, 3, 4, 8])
 def test_benchmarked_path_exactly(tiles_per_cu):
     """the launch sequence bench.py times (bench.py: steady_engine + step) reproduced to the letter -- fp16, O(1)
     weights, in-kernel Philox selectors (setSelectorSeed), conditioning packed chunk-wise from one reused 64-sample block
@@ -629,7 +630,9 @@ def test_benchmarked_path_exactly(tiles_per_cu):
     # utterances against the one-tile kernel run on 1024 utterances, whose first 16 are the oracle-held ones of the other case
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     B = tiles_per_cu * 16 * ncu
-    y = sequence(B, 0, bench.HEADLINE_KERNELS[tiles_per_cu])
+    # (four / eight tiles per CU: beyond the real-time capacity the engine runs wn::wavenet_bcast with one / two tiles per wave on
+    #  every CU -- the launch shapes of bench.py's `oversubscribed` entry, and the full-load stress of its LDS ring protocol)
+    y = sequence(B, 0, bench.HEADLINE_KERNELS.get(tiles_per_cu, "wn::wavenet_bcast<fp16,64,256,256,BTW=%d,EMBLDS=1,DUMP=0>" % (tiles_per_cu // 4)))
     y1k = sequence(1024, util.MODE_ORG["wg"])
     assert np.array_equal(y[:1024], y1k), "the headline batch differs from the one-tile kernel on the benchmarked sequence"
     assert np.array_equal(y1k[:s.B], sequence(s.B, util.MODE_ORG["wg"]))
@@ -950,8 +953,8 @@ def test_full_chip_batches_by_replication(B):
     e.close()
 
 
-@pytest.mark.parametrize("B", [4112, 8208, 12304, 16368, 16400])
-def test_full_chip_batches_by_replication_fp16(B):
+@pytest.mark.parametrize("B,impl", [(4112, 1), (8208, 1), (12304, 1), (16400, 1), (12304, 0), (16368, 0), (16400, 0), (32752, 0)])
+def test_full_chip_batches_by_replication_fp16(B, impl):
     """The same property for the fp16 production path (dump-free kernels, engine's own choice of organisation at
     full-chip batch sizes; O(1) inputs): the big batch must repeat, bit for bit, what the one-tile kernel generates for
     the 19 utterances alone (one, two and three tiles per workgroup perform the same arithmetic per utterance; beyond
@@ -966,6 +969,8 @@ def test_full_chip_batches_by_replication_fp16(B):
     e0.close()
     assert len(np.unique(y0)) > 100
     idx = np.arange(B) % s.B
+    # impl 1 = SINGLE_BLOCK: wavenet_wg whatever the batch; impl 0 = AUTO: beyond three tiles per CU the throughput organisation
+    case = cases.Case(case.name, case.seed, case.prior, case.shape, impl, case.iters, case.chunk)
     e = _engine_o1(case, t, 16, None, B=B, Lh=np.ascontiguousarray(t.Lh[:, :, idx, :]), sel=np.ascontiguousarray(t.sel[:, idx]))
     # the engine reports what it launches: dump-free kernels; two / three tiles per workgroup beyond one / two tiles per CU
     import torch
@@ -974,8 +979,9 @@ def test_full_chip_batches_by_replication_fp16(B):
     info = e.kernelInfo(B, False)
     assert "DUMP=0" in info and "fp16" in info, info
     # ... and beyond three tiles per CU the throughput organisation, wn::wavenet_bcast (two tiles per wave beyond four per CU)
-    want = "BTW=2" if tiles > 4 * ncu else "BTW=1" if tiles > 3 * ncu else "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
-    assert want in info and ("wavenet_bcast<" in info) == (tiles > 3 * ncu), (info, ncu)
+    bc = impl == 0 and tiles > 3 * ncu
+    want = ("BTW=2" if tiles > 4 * ncu else "BTW=1") if bc else "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
+    assert want in info and ("wavenet_bcast<" in info) == bc, (info, ncu)
     y = np.full((B, s.N), -1, dtype=np.int32)
     assert e.run(s.N, B, y, 1, False)
     e.synchronize()
