@@ -300,6 +300,64 @@ def end_to_end_khz(w, B, chunk=256, chunks=4, seed=21):
     return (N / ms) if ok else 0.0
 
 
+def with_producer_khz(w, B, chunk=256, chunks=4, seed=31):
+    """The deployable loop with the conditioning PRODUCER in it (VERDICT r3 #3 i): a WaveNet's conditioning is the output of its
+    own upsampling + 1x1 `cond_layers` convolution (pytorch/wavenet.py:190-202).  Per chunk of `chunk` samples,
+    nv_wavenet.get_cond_input(layout="packed", out=...) runs that model part on the GPU (mel-like features [B][80][frames],
+    fp16 weights with the engine's channel permutation and gate pre-scale folded in) and lands its output in the engine's
+    fragment order inside the buffer the generation kernel reads (setConditioningPacked): no re-layout, no second pass.  Every
+    CU holds a generation workgroup for a whole launch, so the producer of chunk j+1 can only run BETWEEN the generation
+    launches of chunks j and j+1, on the same stream; chunk 0's production is inside the timed region as well.
+    Returns kHz per utterance over chunks * chunk samples."""
+    import torch
+    from nv_wavenet_amd.nv_wavenet import get_cond_input
+    N = chunk * chunks
+    n_cond, stride, window = 80, 256, 1024
+    assert chunk % stride == 0
+    frames = chunk // stride
+    e = build_engine(w, B, N)
+    tiles = e.condTiles()
+    Bp = tiles * 16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    h = torch.float16
+    feats = [(torch.rand(Bp, n_cond, frames, device="cuda", generator=g) - 0.5).to(h) for _ in range(2)]
+    up_w = ((torch.rand(n_cond, n_cond, window, device="cuda", generator=g) - 0.5) * 0.05).to(h)
+    up_b = torch.zeros(n_cond, device="cuda", dtype=h)
+    cw = ((torch.rand(2 * R * L, n_cond, 1, device="cuda", generator=g) - 0.5) * 0.5).to(h)
+    cb = torch.zeros(2 * R * L, device="cuda", dtype=h)
+    frags = torch.zeros(N + 1, L, tiles, 2 * R // 32, 4, 16, 8, dtype=h, device="cuda")
+
+    def produce(j):
+        get_cond_input(feats[j % 2], up_w, up_b, stride, cw, cb, L, layout="packed", precision=16, tiles=tiles,
+                       out=frags[j * chunk:(j + 1) * chunk])
+    produce(0)                                   # warm-up of both paths (kernels, workspaces)
+    torch.cuda.synchronize()
+    e.setConditioningPacked(frags, N)
+    e.setSelectorSeed(seed)
+    st = torch.cuda.current_stream()
+    e.run_partial_chunk(0, min(64, chunk), N, B, st.cuda_stream)
+    torch.cuda.synchronize()
+    e.resetHistory()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    produce(0)
+    for j in range(chunks):
+        assert e.run_partial_chunk(j * chunk, chunk, N, B, st.cuda_stream)
+        if j + 1 < chunks:
+            produce(j + 1)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    y = torch.zeros(B, N, dtype=torch.int32, device="cuda")
+    e.getYOut(y, 0, N, None)
+    torch.cuda.synchronize()
+    ok = int(torch.unique(y).numel()) > 8
+    e.close()
+    del frags, feats
+    torch.cuda.empty_cache()
+    return (N / ms) if ok else 0.0
+
+
 def cpu_run_once(w, n, B=16, seed=5):
     """n samples of the C3 shape at batch B on the calling core: (seconds, kind)."""
     from oracle import oracle as O
@@ -527,6 +585,16 @@ def main():
             refdef[sh.name] = {"single_workgroup": reference_definition_khz(sh, 1),
                                "multi_cu_chain": reference_definition_khz(sh, 3),
                                "auto": reference_definition_khz(sh, 0)}
+            # ... and the largest batch the multi-CU organisation serves at once: one chain of `stages` CUs per 16 utterances, all
+            # of them resident together (what bounds it: CUs / stages chains)
+            import re
+            m = re.search(r"stages=(\d+)", refdef[sh.name]["multi_cu_chain"]["kernel"])
+            if m:
+                chains = ncu // int(m.group(1))
+                big = Shape(sh.name, sh.R, sh.S, sh.A, sh.L, sh.maxD, 16 * chains)
+                r = reference_definition_khz(big, 3, N=4096, chunk=2048)
+                refdef[sh.name]["multi_cu_chain_full_gpu"] = r
+                refdef[sh.name]["max_realtime_batch_multi_cu"] = big.B if r["khz_per_utterance"] >= REALTIME_KHZ and "wavenet_chain" in r["kernel"] else None
         bt = 64 * ncu                                 # four tiles per CU: more workgroups than CUs, not real time
         # beyond three tiles per CU the engine switches to wn::wavenet_bcast (every wave its own tiles, weights broadcast through
         # LDS): throughput, not real time; reported at four and at eight tiles per CU
@@ -551,6 +619,28 @@ def main():
                 best = cand
                 break
         e2e["max_realtime_batch_per_gpu"] = best
+        # ... and with the producer of that conditioning in the loop (the model's own upsampling + conditioning convolution, run on
+        # the GPU between the generation launches, landing in fragment order): what a deployment gets end to end
+        wp = {"definition": "per chunk of 256 samples: get_cond_input(layout='packed') (ConvTranspose1d upsampling of [B][80][frames] "
+                            "fp16 features + the 1x1 conditioning convolution with the engine's channel order and gate pre-scale folded "
+                            "into its weights, torch on the GPU) writes the engine's fragment order in place, then the generation launch "
+                            "of that chunk; same stream (every CU holds a generation workgroup for a whole launch); 4 chunks, the first "
+                            "production inside the timed region", "sweep_khz": {}}
+        best_wp = None
+        for cand in sorted(set([B, B * 3 // 4, B // 2, B * 3 // 8, B // 4]), reverse=True):
+            cand = max(16, cand // 64 * 64)
+            try:
+                k = with_producer_khz(w, cand)
+            except RuntimeError as ex:          # (out of memory in the producer's workspaces at the largest batch)
+                wp["sweep_khz"][str(cand)] = "failed: %s" % str(ex)[:80]
+                torch.cuda.empty_cache()
+                continue
+            wp["sweep_khz"][str(cand)] = k
+            if k >= REALTIME_KHZ:
+                best_wp = cand
+                break
+        wp["max_realtime_batch_per_gpu"] = best_wp
+        e2e["with_producer"] = wp
         # ... and with no pack at all: the kernels read the caller's tensor in place (setConditioningDirect), fp16 (the
         # engine's T_data) or fp32; steady state like the headline, at the headline batch, then at two / one tile per CU
         # until it is real time
@@ -572,8 +662,10 @@ def main():
                                      "real_time": bool(k_ip >= REALTIME_KHZ), "sweep_khz": ip_sweep}
 
     # ---- the timed workload: every step generates samples STEADY_FROM .. STEADY_FROM+N-1 (all dilated taps live, all rings
-    #      wrapped, conditioning rows of exactly those samples) for every utterance, from the state the previous step left
+    #      wrapped, conditioning rows of exactly those samples) for every utterance (re-run per step on the rings the previous step left:
+    #      timing only, see config.workload)
     e, NTOT, _keep = steady_engine(w, B, N, 100 + rank)
+    e.setClockProbe(True)                       # workgroup 0 of every launch records shader / wall clock counters
     kinfo = e.kernelInfo(B, False)
     torch.cuda.empty_cache()
     ybuf = [torch.zeros(B, NTOT, dtype=torch.int32, device="cuda") for _ in range(2)]
@@ -627,6 +719,7 @@ def main():
     ylast = ybuf[(args.steps - 1) % 2][:, STEADY_FROM:]
     hist = int(torch.unique(ylast).numel())
     status = e.chainStatus()
+    clock_ghz = e.lastLaunchClockGHz()          # the clock the last timed launch ran at (the chip clocks to its power budget)
     e.close()
 
     if rank == 0:
@@ -663,6 +756,13 @@ def main():
                         kernel_ms=kern_ms,
                         hbm=dict(achieved=units * HEAD.hbm_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"))
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
+        # measured inside the kernel (s_memtime ticks over s_memrealtime ticks of workgroup 0): under full load the chip
+        # runs this launch below its 2.4 GHz maximum -- power-limited, profiles/r04_clock_*.json -- and `frac` is against the
+        # peak at 2.4 GHz; frac_at_measured_clock prices the same work against the matrix peak at the clock actually granted
+        if clock_ghz > 0:
+            roofline["shader_clock_ghz"] = clock_ghz
+            roofline["shader_cycles_per_sample"] = kern_ms * 1e-3 / N * clock_ghz * 1e9
+            roofline["frac_at_measured_clock"] = roofline["frac"] * 2.4 / clock_ghz
         roofline["hbm"]["frac"] = roofline["hbm"]["achieved"] / HBM_PEAK_GBS
         if not chain_mode:                                      # (the chain reads no weights after its prologue)
             roofline["l2_weight_stream"] = dict(achieved=passes * N * HEAD.weight_bytes / (kern_ms * 1e-3) / 1e9,
@@ -672,7 +772,7 @@ def main():
             # rocprof-reported when this launch shape was profiled: (SQ_INSTS_LDS_LOAD_BANDWIDTH + SQ_INSTS_LDS_STORE_BANDWIDTH) x 64 B
             roofline["lds"] = dict(achieved=(lds_counter or lds_alg) / (kern_ms * 1e-3) / 1e9, peak=LDS_PEAK_GBS, unit="GB/s",
                                    bytes_per_launch=lds_counter or lds_alg, algorithmic_bytes_per_launch=lds_alg,
-                                   source=("rocprofv3 counters of this launch shape (%s, profiles/r03_pmc_wg_b12288.txt)" % traffic_file)
+                                   source=("rocprofv3 counters of this launch shape (%s)" % traffic_file)
                                    if lds_counter else "algorithmic bytes (exchange images, bias quads, logits): this launch shape was not profiled")
             roofline["lds"]["frac"] = roofline["lds"]["achieved"] / LDS_PEAK_GBS
         out = {
@@ -681,7 +781,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.config == "c5" else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "C3: R=64 S=256 A=256 L=20 maxDilation=512 fp16, autoregressive generation at steady state "
-                                   "(each step = samples %d..%d of every utterance: all dilated taps live, all rings wrapped)" % (STEADY_FROM, STEADY_FROM + N - 1)
+                                   "(each step = samples %d..%d of every utterance: all dilated taps live, all rings wrapped; the steps re-run that sample "
+                                   "range -- same launch, same memory traffic -- so from the second step on the rings hold the previous step's "
+                                   "values: a timing workload, not one long utterance)" % (STEADY_FROM, STEADY_FROM + N - 1)
                        if args.config == "headline" else
                        "C5: C3 shape, global batch 64 sharded over the ranks, RCCL gather of the samples",
                        "batch_per_gpu": B, "global_batch": total_batch, "samples_per_step": N,

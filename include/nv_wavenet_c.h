@@ -98,6 +98,10 @@ int nvw_set_conditioning_direct_t(nvw_engine* e, const void* Lh, int num_samples
  * kernels run their packed path on that buffer: no copy, no second pass.  One padding sample past the last; the buffer stays
  * alive and unchanged until the run calls that follow have completed.  Resets the history like nvw_set_inputs. */
 void nvw_set_conditioning_packed(nvw_engine* e, const void* frags, int num_samples);
+/* the same with the buffer's size stated (elements of the engine's T_data): returns 0 and changes nothing unless it holds
+ * (num_samples + 1) x layers x nvw_cond_tiles(e) x 16 x 2R elements.  Either way the run calls that follow refuse (assert, like
+ * the other preconditions of the path) to generate more samples than were handed over here. */
+int nvw_set_conditioning_packed_n(nvw_engine* e, const void* frags, int num_samples, size_t elems);
 int nvw_cond_tiles(nvw_engine* e);
 /* the selector half of nvw_set_inputs ([num_samples][batch] uniform draws, host or device); conditioning and history untouched */
 void nvw_set_selectors(nvw_engine* e, float* output_selectors, int num_samples);

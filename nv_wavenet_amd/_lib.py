@@ -39,6 +39,7 @@ SIGNATURES = {
     "nvw_set_conditioning_direct": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_set_conditioning_direct_t": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "nvw_set_conditioning_packed": (None, [C.c_void_p, _fp, C.c_int]),
+    "nvw_set_conditioning_packed_n": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_size_t]),
     "nvw_cond_tiles": (C.c_int, [C.c_void_p]),
     "nvw_set_selectors": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_chain_status": (C.c_uint, [C.c_void_p]),

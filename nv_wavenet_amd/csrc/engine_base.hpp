@@ -16,6 +16,7 @@ struct nvw_engine {
     virtual void setConditioningDirect(const void*, int, int) = 0;
     virtual void setConditioningPacked(const void*, int) = 0;
     virtual int condTiles() = 0;
+    virtual size_t condPackedElems(int) = 0;
     virtual void setSelectors(float*, int) = 0;
     virtual bool run_range(int, int, int, int, hipStream_t) = 0;
     virtual void resetHistory(hipStream_t) = 0;
@@ -58,6 +59,7 @@ struct EngineImpl : nvw_engine {
     void setConditioningDirect(const void* Lh, int n, int prec) override { eng.setConditioningDirect(Lh, n, prec); }
     void setConditioningPacked(const void* frags, int n) override { eng.setConditioningPacked(frags, n); }
     int condTiles() override { return eng.condTiles(); }
+    size_t condPackedElems(int n) override { return eng.condPackedElems(n); }
     void setSelectors(float* sel, int n) override { eng.setSelectors(sel, n); }
     bool run_range(int i, int c, int n, int b, hipStream_t s) override { return eng.run_range(i, c, n, b, s); }
     void resetHistory(hipStream_t s) override { eng.resetHistory(s); }

@@ -100,6 +100,7 @@ protected:
     const void* m_condRaw;    // or: the caller's [N][L][maxBatch][2R] device tensor, consumed in place (setConditioningDirect)
     int m_condRawKind;        // 1: fp32, 2: fp16 (T_data of the fp16 engine)
     const void* m_condUser;   // or: the caller's device buffer ALREADY in the engine's fragment order (setConditioningPacked)
+    int m_condUserSamples;    // samples that buffer holds (+ one padding sample)
     float* m_outputSelectors;
     elem* m_ring;
     int *m_yInPrev, *m_yInCur, *m_yOut;
@@ -316,7 +317,7 @@ public:
                    bool tanhEmbed = true, int organisation = NVW_ORG_AUTO)
         : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
-          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0), m_condUser(NULL),
+          m_num_samples_per_chunk(0), m_lastStride(numSamples), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0), m_condUser(NULL), m_condUserSamples(0),
           m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0), m_ringShadow(NULL), m_histShadow(NULL),
           m_chainTimeoutTicks(wn::kChainTimeoutTicks), m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL),
           m_mulaw(NULL), m_pcmUser(NULL), m_pcmUserElems(0), m_clk(NULL), m_clkOn(false), m_stageUsed(0) {
@@ -568,7 +569,9 @@ public:
         if (!m_cond) {
             const size_t condElems = (size_t)(m_maxSamples + 1) * m_numLayers * dstPerRow;   // + one padding sample
             gpuErrChk(hipMalloc(&m_cond, condElems * sizeof(elem)));
+            // zeroed before ANY stream may pack into it (a later chunk packed on another stream must not be overtaken by this)
             gpuErrChk(hipMemsetAsync(m_cond, 0, condElems * sizeof(elem), stream));
+            gpuErrChk(hipStreamSynchronize(stream));
         }
         elem* const dst0 = m_cond + (size_t)firstSample * m_numLayers * dstPerRow;
         const bool dev = isDevicePtr(Lh);
@@ -628,7 +631,10 @@ public:
         m_condRaw = NULL;
         m_condRawKind = 0;
         m_condUser = frags;
+        m_condUserSamples = numSamples;      // (run_partial refuses to generate past what the caller handed over)
     }
+    // elements (T_data) a packed buffer of numSamples samples must hold: (numSamples + 1) x L x condTiles() x 16 x 2R
+    size_t condPackedElems(int numSamples) const { return (size_t)(numSamples + 1) * m_numLayers * m_tiles * 16 * 2 * R; }
     // tiles of 16 utterances per (sample, layer) row of the packed conditioning (the batch rounded up to whole workgroups)
     int condTiles() const { return m_tiles; }
     bool conditioningInPlace() const { return m_condRaw != NULL; }
@@ -799,6 +805,7 @@ public:
         assert(num_samples <= m_maxSamples);
         assert(m_condRaw != NULL || m_cond != NULL || m_condUser != NULL);  // some conditioning has been handed over
         assert(m_condRaw == NULL || num_samples <= m_condRawSamples);      // ... and the in-place tensor covers the run
+        assert(m_condUser == NULL || num_samples <= m_condUserSamples);    // ... and so does a caller's packed buffer
         assert(m_pcmUser == NULL || m_pcmUserElems == 0 || m_pcmUserElems >= (size_t)batch_size * num_samples);
         if (m_implementation == SINGLE_BLOCK) assert(S <= 4 * R);
         if (!m_supported) return false;

@@ -91,10 +91,27 @@ int nvw_set_conditioning_direct_t(nvw_engine* e, const void* Lh, int num_samples
                 e->precisionBits());
         return 0;
     }
+    if (precision == 16) {      // (a host tensor can only take the packing path, which reads fp32)
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, Lh) != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)) {
+            (void)hipGetLastError();
+            fprintf(stderr, "nvw_set_conditioning_direct_t: an fp16 tensor must be device memory to be read in place\n");
+            return 0;
+        }
+    }
     e->setConditioningDirect(Lh, num_samples, precision);
     return 1;
 }
 void nvw_set_conditioning_packed(nvw_engine* e, const void* frags, int num_samples) { e->setConditioningPacked(frags, num_samples); }
+int nvw_set_conditioning_packed_n(nvw_engine* e, const void* frags, int num_samples, size_t elems) {
+    if (num_samples <= 0 || elems < e->condPackedElems(num_samples)) {
+        fprintf(stderr, "nvw_set_conditioning_packed_n: %zu elements cannot hold %d samples (+1) in this engine's fragment order (%zu needed)\n",
+                elems, num_samples, num_samples > 0 ? e->condPackedElems(num_samples) : (size_t)0);
+        return 0;
+    }
+    e->setConditioningPacked(frags, num_samples);
+    return 1;
+}
 int nvw_cond_tiles(nvw_engine* e) { return e->condTiles(); }
 void nvw_set_selectors(nvw_engine* e, float* sel, int num_samples) { e->setSelectors(sel, num_samples); }
 unsigned nvw_chain_status(nvw_engine* e) { return e->chainStatus(); }

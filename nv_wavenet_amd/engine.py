@@ -153,7 +153,8 @@ class WavenetEngine:
         assert 0 < ns <= self.maxSamples
         assert frags.numel() == (ns + 1) * self.numLayers * self.condTiles() * 16 * 2 * self.R, "fragment tensor has the wrong size"
         self._cond_keep = frags
-        lib.nvw_set_conditioning_packed(self._h, addr(frags), ns)
+        if not lib.nvw_set_conditioning_packed_n(self._h, addr(frags), ns, frags.numel()):
+            raise ValueError("the fragment tensor is too small for %d samples" % ns)
 
     def setSelectors(self, outputSelectors, numSamples=None):
         """The selector half of setInputs: [numSamples][maxBatch] uniform draws; conditioning and history untouched."""

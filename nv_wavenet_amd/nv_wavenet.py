@@ -130,15 +130,22 @@ def cond_fragment_order(R, precision=16):
     return perm, scale
 
 
-def _fragments_from_ordered(x, tiles, dtype):
+def _fragments_from_ordered(x, tiles, dtype, out=None):
     """x [N][L][B][2R] with the channels already in fragment order (and pre-scaled) -> the engine's packed tensor
-    [N + 1][L][tiles][wave][fragment][g][j][EPL] (one zero padding sample, utterances padded to whole tiles)."""
+    [N + 1][L][tiles][wave][fragment][g][j][EPL] (one zero padding sample, utterances padded to whole tiles).
+    out: N samples of an existing packed tensor ([N][L][tiles][wave*fragment][g][j][EPL], e.g. a slice of the buffer handed to
+    setConditioningPacked) to write into instead: the permuting copy lands there directly (a producer that streams the
+    conditioning chunk by chunk into one long buffer)."""
     N, L, B, C2 = x.shape
     EPL = 8 if dtype == torch.float16 else 4
-    out = torch.zeros(N + 1, L, tiles * 16, C2, dtype=dtype, device=x.device)
-    out[:N, :, :B] = x.to(dtype)
-    out = out.view(N + 1, L, tiles, 16, C2 // (4 * EPL), 4, EPL)          # [n][l][tile][j][wave*fragment][g][e]
-    return out.permute(0, 1, 2, 4, 5, 3, 6).contiguous()                    # [n][l][tile][wave*fragment][g][j][e]
+    if out is not None:
+        assert B == tiles * 16, "writing into a packed buffer needs whole tiles (pad the batch)"
+        out.copy_(x.view(N, L, tiles, 16, C2 // (4 * EPL), 4, EPL).permute(0, 1, 2, 4, 5, 3, 6))
+        return out
+    buf = torch.zeros(N + 1, L, tiles * 16, C2, dtype=dtype, device=x.device)
+    buf[:N, :, :B] = x.to(dtype)
+    buf = buf.view(N + 1, L, tiles, 16, C2 // (4 * EPL), 4, EPL)          # [n][l][tile][j][wave*fragment][g][e]
+    return buf.permute(0, 1, 2, 4, 5, 3, 6).contiguous()                    # [n][l][tile][wave*fragment][g][j][e]
 
 
 def pack_cond_input(cond_nlbc, precision, tiles):
@@ -156,7 +163,7 @@ def pack_cond_input(cond_nlbc, precision, tiles):
 
 
 def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, cond_weight, cond_bias, n_layers,
-                   layout="CBLN", dtype=None, precision=16, tiles=None):
+                   layout="CBLN", dtype=None, precision=16, tiles=None, out=None):
     """WaveNet.get_cond_input (pytorch/wavenet.py:190-202) as a function of the module's tensors,
     run wherever `features` lives (the GPU): ConvTranspose1d upsampling, trimming of the
     (kernel - stride) transposed-convolution tail, the 1x1 `cond_layers` convolution.
@@ -182,7 +189,13 @@ def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, co
         sc = torch.tensor(scale, dtype=cond_weight.dtype, device=cond_weight.device)
         w = cond_weight.view(n_layers, C2, cond_weight.size(1), 1).index_select(1, idx) * sc[None, :, None, None]
         b = cond_bias.view(n_layers, C2).index_select(1, idx) * sc[None, :]
-        x = F.conv1d(x, w.reshape(n_layers * C2, cond_weight.size(1), 1), b.reshape(-1))
+        x = F.conv1d(x, w.reshape(n_layers * C2, cond_weight.size(1), 1), b.reshape(-1))        # [B][L * 2R][N]
+        if out is not None:
+            # straight into N samples of an existing packed buffer: [tile][j][l][wave*fragment][g][e][n] -> [n][l][tile][wf][g][j][e]
+            EPL = 8 if precision == 16 else 4
+            assert x.size(0) == tiles * 16, "writing into a packed buffer needs whole tiles (pad the batch)"
+            out.copy_(x.view(tiles, 16, n_layers, C2 // (4 * EPL), 4, EPL, x.size(2)).permute(6, 2, 0, 3, 4, 1, 5))
+            return out
         x = x.view(x.size(0), n_layers, C2, x.size(2)).permute(3, 1, 0, 2)            # [N][L][B][2R], fragment channel order
         return _fragments_from_ordered(x, tiles, torch.float16 if precision == 16 else torch.float32)
     x = F.conv1d(x, cond_weight, cond_bias)

@@ -57,3 +57,41 @@ def gather_samples(y_local, total_batch, group=None, async_op=False):
         return res.to(dev) if res.device != dev else res
 
     return (None, finish) if async_op else (finish(), None)
+
+
+class ChunkGatherer:
+    """Streaming form of gather_samples for run_chunks ("with run_chunks, gather per chunk"): every finished chunk
+    of `count` samples is gathered on its own -- columns [first, first + count) of every rank's [b_local][N] block -- while the
+    next chunk is generated, so the full [B][N] result is complete one collective after the last chunk instead of one whole-
+    utterance collective at the end.  Use as the consumer callback of run_chunks:
+
+        g = ChunkGatherer(total_batch, num_samples, y_local)      # y_local: the rank's [b_local][N] output buffer (host or device)
+        engine.run_chunks(chunk, g, num_samples, b_local, y_local)
+        y_full = g.finish()                                       # [total_batch][num_samples] on every rank
+
+    At most `depth` collectives are in flight (the oldest is completed before a new one starts)."""
+
+    def __init__(self, total_batch, num_samples, y_local, group=None, depth=2):
+        self.total, self.N, self.y_local, self.group, self.depth = total_batch, num_samples, y_local, group, depth
+        self.full = None
+        self.pending = []          # (first, count, finish)
+
+    def _land(self):
+        first, count, fin = self.pending.pop(0)
+        blk = fin()
+        if self.full is None:
+            self.full = torch.zeros(self.total, self.N, dtype=blk.dtype, device=blk.device)
+        self.full[:, first:first + count] = blk
+
+    def __call__(self, y_out, first, count):
+        y = self.y_local if self.y_local is not None else y_out
+        y = torch.as_tensor(y)
+        while len(self.pending) >= self.depth:
+            self._land()
+        _, fin = gather_samples(y[:, first:first + count].contiguous(), self.total, self.group, async_op=True)
+        self.pending.append((first, count, fin))
+
+    def finish(self):
+        while self.pending:
+            self._land()
+        return self.full

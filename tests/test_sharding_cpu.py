@@ -50,6 +50,12 @@ def _worker(rank, world, port, total_batch, q):
         y_full, _ = gather_samples(y_local, total_batch)
         _, fin = gather_samples(y_local, total_batch, async_op=True)
         assert torch.equal(fin(), y_full)
+        # the streaming form (run_chunks: one gather per finished chunk, ragged last chunk): same result
+        from nv_wavenet_amd.sharding import ChunkGatherer
+        g = ChunkGatherer(total_batch, s.N, y_local)
+        for first in range(0, s.N, 3):
+            g(None, first, min(3, s.N - first))
+        assert torch.equal(g.finish(), y_full)
         if rank == 0:
             q.put(y_full.numpy())
     finally:
