@@ -595,12 +595,13 @@ def main():
                 r = reference_definition_khz(big, 3, N=4096, chunk=2048)
                 refdef[sh.name]["multi_cu_chain_full_gpu"] = r
                 refdef[sh.name]["max_realtime_batch_multi_cu"] = big.B if r["khz_per_utterance"] >= REALTIME_KHZ and "wavenet_chain" in r["kernel"] else None
-        bt = 64 * ncu                                 # four tiles per CU: more workgroups than CUs, not real time
-        # beyond three tiles per CU the engine switches to wn::wavenet_bcast (every wave its own tiles, weights broadcast through
-        # LDS): throughput, not real time; reported at four and at eight tiles per CU
+        bt = 64 * ncu                                 # four tiles per CU: not real time
+        # between three and four tiles per CU the engine runs one round of wn::wavenet_bcast workgroups (every wave its own tile,
+        # weights broadcast through LDS); beyond that, whole rounds of three-tile wavenet_wg workgroups: throughput, not real
+        # time; reported at four and at six tiles per CU (= two full rounds)
         thr = {"definition": "batches beyond the real-time capacity: more utterances per GPU at a lower rate per utterance "
                              "(steady state, samples 640..1151; the engine's own choice of organisation)", "points": []}
-        for bt_ in (bt, 2 * bt):
+        for bt_ in (bt, 96 * ncu):
             khz_t, info_t = measure_steady_khz(w, bt_, 256)
             thr["points"].append({"batch_per_gpu": bt_, "khz_per_utterance": khz_t, "samples_per_sec_per_gpu": bt_ * khz_t * 1e3,
                                   "kernel": info_t.split(" ")[0], "real_time": bool(khz_t >= REALTIME_KHZ)})

@@ -58,11 +58,11 @@ enum nvwOrganisation {
     NVW_ORG_WG3 = 4,      // wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64; else two)
     NVW_ORG_CHAIN = 5,    // wn::wavenet_chain, as many layers per CU as stay resident
     NVW_ORG_CHAIN1 = 6,   // wn::wavenet_chain, one layer per CU
-    NVW_ORG_BCAST = 7,    // wn::wavenet_bcast: every wave runs the whole network for its own tiles, weights broadcast through an
-                          // LDS ring; one or two tiles per wave by batch size (R = 64 shapes; others run wavenet_wg)
-    NVW_ORG_BCAST1 = 8,   // ... exactly one tile per wave (4 per workgroup)
-    NVW_ORG_BCAST2 = 9,   // ... two tiles per wave (8 per workgroup; fp16)
-    NVW_ORG_LAST = NVW_ORG_BCAST2
+    NVW_ORG_BCAST = 7,    // wn::wavenet_bcast: every wave runs the whole network for its own tile (4 per workgroup), weights
+                          // broadcast through an LDS ring (R = 64 shapes; others run wavenet_wg)
+    NVW_ORG_BCAST1 = 8,   // (the same: kept from the time a two-tiles-per-wave variant existed)
+    NVW_ORG_RETIRED9 = 9, // was: two tiles per wave (measured no faster than two rounds of one tile per wave; removed) -- refused
+    NVW_ORG_LAST = NVW_ORG_BCAST1
 };
 
 template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
@@ -246,10 +246,11 @@ protected:
     // a CU streams 58 B/clk of weights at ~2.1 GHz beside ~0.45 us of dependent chain per layer; a chain
     // stage costs one ~1.1 us hand-off plus ~0.5 us per layer with resident weights.
     int pickOrganisation(int tiles) const {
-        // beyond what wavenet_wg serves in real time (three tiles per CU) the job is throughput: every wave its own tiles, the
-        // weights broadcast through LDS (measured, C3 fp16: 335 against 230 M samples/s at 32 768 / 16 384 utterances)
-        if constexpr (F16 && BC2) {
-            if (tiles > 3 * m_numCUs && bcastFits()) return NVW_ORG_BCAST;
+        // beyond what wavenet_wg serves in one round of workgroups (three tiles per CU) and up to four tiles per CU, one round of
+        // wavenet_bcast (four tiles per workgroup) beats two rounds of wavenet_wg (measured, C3 fp16 at 16 384 utterances: 54 us
+        // against 2 x 36.5 us per sample); beyond that, whole rounds of three-tile workgroups win again (kOrgTimes)
+        if constexpr (F16 && BC1) {
+            if (tiles > 3 * m_numCUs && tiles <= 4 * m_numCUs && bcastFits()) return NVW_ORG_BCAST;
         }
         const int single = singleOrg(tiles);
         const int lpc = chainLpcMax(m_numLayers);
@@ -276,7 +277,7 @@ protected:
         }
         if (org == NVW_ORG_CHAIN && !chainFits(chainLpcMax(m_numLayers), tiles)) org = singleOrg(tiles);
         if (org == NVW_ORG_CHAIN1 && !(CC::SUPPORTED && chainFits(1, tiles))) org = singleOrg(tiles);
-        if (org >= NVW_ORG_BCAST && org <= NVW_ORG_BCAST2 && !bcastFits()) org = singleOrg(tiles);
+        if (org >= NVW_ORG_BCAST && org <= NVW_ORG_BCAST1 && !bcastFits()) org = singleOrg(tiles);
         m_org = org;
         m_chainLpc = org == NVW_ORG_CHAIN ? chainLpcMax(m_numLayers) : org == NVW_ORG_CHAIN1 ? 1 : 0;
         m_chainStages = m_chainLpc ? chainStagesFor(m_numLayers, m_chainLpc) : 0;
@@ -284,20 +285,12 @@ protected:
     bool isChain() const { return m_chainLpc > 0; }
     // ---- wn::wavenet_bcast ------------------------------------------------------------------------------------------
     static constexpr bool BC1 = wn::BCfg<F16, R, S, A, 1>::SUPPORTED;
-    static constexpr bool BC2 = F16 && wn::BCfg<F16, R, S, A, 2>::SUPPORTED;      // (two tiles per wave: the fp16 engine)
-    bool isBcast() const { return m_org >= NVW_ORG_BCAST && m_org <= NVW_ORG_BCAST2; }
+    bool isBcast() const { return m_org >= NVW_ORG_BCAST && m_org <= NVW_ORG_BCAST1; }
     template <int BTW> static size_t bcastLds(int L, bool dump, int emb) { return wn::BCfg<F16, R, S, A, BTW>::ldsBytes(L, dump, emb); }
     // the shape has the kernel, the model is deep enough for its two-layer lookahead and its tables fit the LDS beside the ring
     bool bcastFits() const {
         if constexpr (BC1) return m_numLayers >= 3 && bcastLds<1>(m_numLayers, true, 0) <= kLdsMax;
         return false;
-    }
-    // tiles per wave for a batch of `tiles` tiles
-    int bcastTiles(int tiles) const {
-        if constexpr (BC2) {
-            if (m_org == NVW_ORG_BCAST2 || (m_org == NVW_ORG_BCAST && tiles > 4 * m_numCUs)) return 2;
-        }
-        return 1;
     }
     // tiles per workgroup of wn::wavenet_wg for a batch of `tiles` tiles
     static constexpr bool WG3 = F16 && R <= 64;   // shapes with a three-tile instantiation
@@ -343,7 +336,7 @@ public:
         // exactly the tiles of the batch
         {
             const int tiles = (batchSize + 15) / 16;
-            const int group = isChain() ? 1 : isBcast() ? 4 * bcastTiles(tiles) : wgTiles(tiles);
+            const int group = isChain() ? 1 : isBcast() ? 4 : wgTiles(tiles);
             m_tiles = (tiles + group - 1) / group * group;
         }
 
@@ -416,7 +409,6 @@ public:
 
         if (isBcast()) {
             if constexpr (BC1) allowBcast<1>();
-            if constexpr (BC2) allowBcast<2>();
         }
         if (ldsFits<1>()) {            // (a chain engine launches wavenet_wg as its fallback)
             allowLds<1>();
@@ -694,11 +686,11 @@ public:
             return;
         }
         if (isBcast() && !m_condRaw) {
-            const int btw = bcastTilesFor(tiles, dump);
-            const int emb = bcastEmb(btw, dump);
+            const int btw = 1;
+            const int emb = bcastEmb(dump);
             snprintf(buf, n, "wn::wavenet_bcast<%s,%d,%d,%d,BTW=%d,EMBLDS=%d,DUMP=%d> tiles/wave=%d wgs=%d lds=%zu", F16 ? "fp16" : "fp32", R, S,
                      A, btw, emb, dump ? 1 : 0, btw, (tiles + 4 * btw - 1) / (4 * btw),
-                     btw == 2 ? bcastLdsAny<2>(dump, emb) : bcastLdsAny<1>(dump, emb));
+                     bcastLdsAny<1>(dump, emb));
             return;
         }
         const int bt = wgTiles(tiles);
@@ -910,15 +902,12 @@ protected:
         gpuErrChk(hipMemcpy(&s, m_chainStatus + i, sizeof(unsigned), hipMemcpyDeviceToHost));
         return s;
     }
-    // wavenet_bcast: one or two tiles per wave by batch size; the current tap's embedding table in LDS when there is room
+    // wavenet_bcast: the current tap's embedding table in LDS when there is room
     template <int BTW> size_t bcastLdsAny(bool dump, int emb) const {
-        if constexpr (BTW == 1 ? BC1 : BC2) return bcastLds<BTW>(m_numLayers, dump, emb);
+        if constexpr (BC1) return bcastLds<BTW>(m_numLayers, dump, emb);
         return 0;
     }
-    int bcastEmb(int btw, bool dump) const {
-        const size_t need = btw == 2 ? bcastLdsAny<2>(dump, 1) : bcastLdsAny<1>(dump, 1);
-        return need <= kLdsMax ? 1 : 0;
-    }
+    int bcastEmb(bool dump) const { return bcastLdsAny<1>(dump, 1) <= kLdsMax ? 1 : 0; }
     template <int BTW, bool EMB, bool DUMP> void allowBcastK() {
         const size_t need = bcastLds<BTW>(m_numLayers, DUMP, EMB ? 1 : 0);
         if (need <= kLdsMax)
@@ -926,10 +915,8 @@ protected:
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
     template <int BTW> void allowBcast() {
-        if constexpr (BTW == 1) {       // (launches that dump activations always run one tile per wave)
-            allowBcastK<BTW, false, true>();
-            allowBcastK<BTW, true, true>();
-        }
+        allowBcastK<BTW, false, true>();
+        allowBcastK<BTW, true, true>();
         if constexpr (F16) {
             allowBcastK<BTW, false, false>();
             allowBcastK<BTW, true, false>();
@@ -945,20 +932,13 @@ protected:
     template <int BTW> bool launchBcastB(wn::Params& p, int tiles, hipStream_t stream) {
         bool dump = true;
         if constexpr (F16) dump = p.dump != 0;
-        const bool emb = bcastEmb(BTW, dump) != 0;
+        const bool emb = bcastEmb(dump) != 0;
         if constexpr (F16) {
             if (!dump) return emb ? launchBcastK<BTW, true, false>(p, tiles, stream) : launchBcastK<BTW, false, false>(p, tiles, stream);
         }
-        if constexpr (BTW == 1) return emb ? launchBcastK<BTW, true, true>(p, tiles, stream) : launchBcastK<BTW, false, true>(p, tiles, stream);
-        return false;
+        return emb ? launchBcastK<BTW, true, true>(p, tiles, stream) : launchBcastK<BTW, false, true>(p, tiles, stream);
     }
-    // (a launch that dumps activations runs one tile per wave whatever the batch: the two-tile kernel has no registers for the dump;
-    //  ring, conditioning and history are laid out per tile, so the launches of one engine may mix the two)
-    int bcastTilesFor(int tiles, bool dump) const { return dump ? 1 : bcastTiles(tiles); }
     bool launchBcast(wn::Params& p, int tiles, hipStream_t stream) {
-        if constexpr (BC2) {
-            if (bcastTilesFor(tiles, p.dump != 0) == 2) return launchBcastB<2>(p, tiles, stream);
-        }
         if constexpr (BC1) return launchBcastB<1>(p, tiles, stream);
         return false;
     }

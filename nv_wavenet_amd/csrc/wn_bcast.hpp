@@ -69,35 +69,74 @@ struct BCfg {
     static constexpr int RAP = 2;                          // read-ahead of the fragment FIFO, in positions
     static constexpr int CH = bc_largest_divisor_le(NSLOT, NSLOT / 4 < 4 ? NSLOT / 4 : 4);   // positions per chunk (<= 4: offset field)
     static constexpr int NCH = NSLOT / CH;
-    static constexpr int E = 3;                            // other vector-memory operations issued with every chunk's copies
+    static constexpr int E = 3;                            // conditioning / tap loads a chunk boundary issues at most
     static constexpr int REQ_LOADS = BTW * (NQ * C::COND_FR + KF_R);    // conditioning + tap fragments of one (sample, layer)
     static constexpr int REQ_GROUPS = (REQ_LOADS + E - 1) / E;
     // boundaries (= groups) inside the part of a generic layer / of layer 0
     static constexpr int GROUPS_L = FLW / CH, GROUPS_L0 = P0_END / CH;
+    // loads of layer 0's request that its own groups cannot hold: issued by the last boundary of the previous sample's head
+    static constexpr int REQ_HEAD = REQ_LOADS - GROUPS_L0 * E > 0 ? REQ_LOADS - GROUPS_L0 * E : 0;
+    // ---- what every chunk boundary issues, and the hand-placed waits that follow from it ----------------------------------
+    // The stream of a sample falls into parts: layer 0 (positions 0 .. P0_END-1), the generic layers (P_CUR .. P_CUR+FLW-1
+    // each, relative to a multiple of FLW), the tail (skip GEMM of the last layer: P_CUR .. FLW-1) and the head (0 .. FHWP-1,
+    // relative to the head's start).  A boundary sits behind every CH-th position (absolute numbering: BP = position + 1 is a
+    // multiple of CH) and issues the next loads of the conditioning / tap request its part carries -- nothing where there is
+    // nothing to request (round 4 began with dummy loads that kept every boundary at E operations: a third of the kernel's
+    // vector-memory instructions).
+    static constexpr int PART_L0 = 0, PART_GEN = 1, PART_TAIL = 2, PART_HEAD = 3;
+    __host__ __device__ static constexpr int reqInGroup(int gi, int first) {     // loads [first + gi E, first + (gi+1) E) of a request that exist
+        const int n = REQ_LOADS - first - gi * E;
+        return gi < 0 || n < 0 ? 0 : n > E ? E : n;
+    }
+    static constexpr int BP0_GEN = (P_CUR / CH + 1) * CH;          // first boundary of a generic layer's part (and of the tail)
+    __host__ __device__ static constexpr int opsAt(int part, int BP) {
+        return part == PART_GEN ? reqInGroup((BP - BP0_GEN) / CH, 0)
+             : part == PART_L0 ? reqInGroup(BP / CH - 1, REQ_HEAD)
+             : part == PART_HEAD ? (BP == FHWP ? REQ_HEAD : 0)
+                                 : 0;
+    }
+    // operations of the i-th boundary in front of the one at BP -- where that boundary lies in the part before, a LOWER bound
+    // over the parts that can come before (a wait that allows fewer operations in flight than were issued is only stricter):
+    // in front of a generic layer or the tail a generic layer is assumed (layer 0's last boundaries issue at least as much:
+    // asserted below), in front of layer 0 the head, in front of the head the tail
+    __host__ __device__ static constexpr int opsBefore(int part, int BP, int i) {
+        const int b = BP - i * CH;
+        return part == PART_GEN || part == PART_TAIL ? (b >= BP0_GEN ? opsAt(part, b) : opsAt(PART_GEN, b + FLW))
+             : part == PART_L0 ? (b >= CH ? opsAt(PART_L0, b) : b == 0 ? REQ_HEAD : 0)
+                               : 0;
+    }
     // before barrier k: own copies of chunk k+2 landed.  Its pieces were issued one per position while chunk k+2-NCH+1 was
-    // consumed (consume); behind the last of them: the E operations of the boundary that ended that chunk, NCH-4 whole chunks
-    // (CH pieces + E operations each) and the CH pieces of chunk k itself
-#ifndef WN_BC_WAITB
-    static constexpr int kWaitBoundary = (NCH - 3) * (CH + E);
-#else
-    static constexpr int kWaitBoundary = WN_BC_WAITB;      // (experiment: a stricter wait)
-#endif
-    // conditioning / taps of layer l+2 are used behind the boundary in front of the tap GEMM at the end of layer l+1.  A
-    // request issued by a generic layer fills the first REQ_GROUPS groups of the layer; the one issued by layer 0 ends in the
-    // last group of layer 0's part: the youngest load of a request is followed by at least the groups of layer l+1 up to
-    // that boundary
+    // consumed (consume); behind the last of them: the loads of the boundary that ended that chunk, NCH-4 whole chunks (CH
+    // pieces and their boundary's loads each) and the CH pieces of chunk k itself
+    __host__ __device__ static constexpr int waitAt(int part, int BP) {
+        int n = (NCH - 3) * CH;
+        for (int i = 1; i <= NCH - 3; i++) n += opsBefore(part, BP, i);
+        return n;
+    }
+    // conditioning / taps of layer l+2 are used behind the boundary in front of the tap GEMM at the end of layer l+1: the
+    // youngest load of a request is followed by at least the pieces and the loads of layer l+1 up to that boundary (where
+    // layer 0 is the user, by the whole head)
     static constexpr int USE_GROUPS = P_PREV / CH - P_CUR / CH;          // boundaries of a generic layer's part in front of its tap GEMM
+    __host__ __device__ static constexpr int useWait() {
+        int n = P_PREV - P_CUR;
+        for (int gi = 0; gi < USE_GROUPS; gi++) n += reqInGroup(gi, 0);
+        return n;
+    }
 #ifndef WN_BC_WAITU
-    static constexpr int kWaitUse = USE_GROUPS * (CH + E);
+    static constexpr int kWaitUse = useWait();
 #else
     static constexpr int kWaitUse = WN_BC_WAITU;
 #endif
-    // loads of layer 0's request that its own groups cannot hold: issued by the last boundary of the previous sample's head
-    static constexpr int REQ_HEAD = REQ_LOADS - GROUPS_L0 * E > 0 ? REQ_LOADS - GROUPS_L0 * E : 0;
+    __host__ __device__ static constexpr bool tailsOrdered() {      // layer 0's last boundaries against a generic layer's (opsBefore)
+        for (int i = 0; i < NCH - 3 && i < GROUPS_L0; i++)
+            if (reqInGroup(GROUPS_L0 - 1 - i, REQ_HEAD) < reqInGroup(GROUPS_L - 1 - i, 0)) return false;
+        return true;
+    }
     static constexpr bool SUPPORTED =
-        R == 64 && NQ == 4 && A <= 256 && S <= 256 && BTW >= 1 && BTW <= 2 && NSLOT >= 8 && NCH >= 4 && CH >= RAP && P_CUR % RAP == 0 &&
+        R == 64 && NQ == 4 && A <= 256 && S <= 256 && BTW == 1 && NSLOT >= 8 && NCH >= 4 && CH >= RAP && CH <= 4 && P_CUR % RAP == 0 &&
         FLW % RAP == 0 && FHWP % RAP == 0 && REQ_HEAD <= E && REQ_GROUPS <= GROUPS_L && P_PREV % CH == 0 &&
-        P0_PREV % CH == 0 && kWaitBoundary <= 63 && kWaitUse <= 63;
+        P0_PREV % CH == 0 && FLW % CH == 0 && FHWP >= (NCH - 3) * CH && GROUPS_L0 >= NCH - 3 && tailsOrdered() &&
+        (NCH - 3) * (CH + E) <= 63 && kWaitUse <= 63 && FW_SKIP + FHWP + P0_PREV >= kWaitUse;
     // gate tile of fragment-local slot `it` of stream q (Cfg: a wave's rows come in (tanh tile, sigmoid tile) pairs)
     __host__ __device__ static constexpr int gateTile(int q, int it) { return q + NQ * (it >> 1) + (it & 1) * RT; }
     // ---- LDS layout (bytes) -------------------------------------------------------------------------------------------
@@ -135,44 +174,41 @@ struct BCfg {
 #define WN_BC_RES                                                                                                                   \
     WN_BC_R10(16), WN_BC_R10(17), WN_BC_R10(18), WN_BC_R10(19), WN_BC_R10(20), WN_BC_R10(21), WN_BC_R10(22), WN_BC_R10(23), WN_BC_R10(24), \
         "a250", "a251", "a252", "a253", "a254", "a255", "a159"
-constexpr int kBcCdReg = 160, kBcXpReg = 224;       // (a159: where the dummy loads below put their word)
+constexpr int kBcCdReg = 160, kBcXpReg = 224;
 __host__ __device__ constexpr int bc_cd_reg(int set, int i) { return kBcCdReg + 32 * set + 4 * i; }
 __host__ __device__ constexpr int bc_xp_reg(int set, int i) { return kBcXpReg + 16 * set + 4 * i; }
 
-// CH consecutive 1-KiB pieces of the wave's stream (at src, wave-uniform) -> LDS at ldsDst: lane l's 16 bytes land at M0 + 16 l, and M0
-// reaches the whole 160 KiB (scripts/ubench/ldsdma_addr.hip; the instruction's offset field would move source AND destination).
+// 1-KiB pieces of the wave's stream (at src, wave-uniform) -> LDS: lane l's 16 bytes land at M0 + 16 l, and M0 reaches the whole
+// 160 KiB (scripts/ubench/ldsdma_addr.hip).
 // Timing experiments (results are wrong with any of them): WN_BC_ABL_NODMA no weight copies; WN_BC_ABL_NOBAR no chunk barriers /
-// waits; WN_BC_ABL_NOFIFO no fragment reads from LDS; WN_BC_ABL_NOREQ no conditioning / tap / dummy loads, no ring stores
-WN_DEV void bc_dma1(unsigned ldsDst, unsigned voff, const char* src) {
+// waits; WN_BC_ABL_NOFIFO no fragment reads from LDS; WN_BC_ABL_NOREQ no conditioning / tap loads, no ring stores
+// Piece J of a chunk: the instruction's offset field moves source AND destination (scripts/ubench/ldsdma_addr.hip), and the pieces
+// of a chunk are consecutive in the stream as in the ring, so all of them share M0 (= LDS address of the chunk's first slot: the
+// wave's ring base + a constant, one scalar add) and the source offset register `voff` (= lane * 16 + the chunk's position in the
+// stream, advanced once per chunk).  Two instructions per piece; the first version paid six scalar ones on top of the copy.
+template <int SLOT0, int J> WN_DEV void bc_dma_piece(unsigned ringMine, unsigned voff, const char* src) {
+    static_assert(J >= 0 && J * 1024 < 4096, "offset field");
 #ifndef WN_BC_ABL_NODMA
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsDst), "v"(voff), "s"(src) : "memory", WN_BC_RES);
+    asm volatile("s_add_u32 m0, %0, %1\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4" ::"s"(ringMine), "n"(SLOT0 * 1024), "v"(voff), "s"(src), "n"(J * 1024)
+                 : "memory", "scc", WN_BC_RES);
 #endif
 }
-template <int CH> WN_DEV void bc_dma(unsigned ldsDst, unsigned lane16, const char* src) {
-    static_assert(CH >= 1 && CH <= 4, "pieces per chunk");
-    bc_dma1(ldsDst, lane16, src);
-    if constexpr (CH > 1) bc_dma1(ldsDst + 1024u, lane16 + 1024u, src);
-    if constexpr (CH > 2) bc_dma1(ldsDst + 2048u, lane16 + 2048u, src);
-    if constexpr (CH > 3) bc_dma1(ldsDst + 3072u, lane16 + 3072u, src);
-}
 // one 16-byte-per-lane load into the fixed accumulator quad a[REG:REG+3], streaming policy; valid only behind a bc_wait_set
+#ifndef WN_BC_LD_AUX
+#define WN_BC_LD_AUX " nt"
+#endif
+#ifndef WN_BC_ST_AUX
+#define WN_BC_ST_AUX " nt"
+#endif
 template <int REG> WN_DEV void bc_load_fixed(unsigned voff, rsrc_t rs, unsigned soff) {
     static_assert(REG >= kBcCdReg && REG + 3 <= 255 && REG % 4 == 0, "fixed register map");
 #ifndef WN_BC_ABL_NOREQ
-    asm volatile("buffer_load_dwordx4 a[%0:%1], %2, %3, %4 offen nt" ::"n"(REG), "n"(REG + 3), "v"(voff), "s"(rs), "s"(soff) : "memory", WN_BC_RES);
+    asm volatile("buffer_load_dwordx4 a[%0:%1], %2, %3, %4 offen" WN_BC_LD_AUX ::"n"(REG), "n"(REG + 3), "v"(voff), "s"(rs), "s"(soff) : "memory", WN_BC_RES);
 #endif
 }
 WN_DEV void bc_store(floatx4 v, unsigned voff, rsrc_t rs, unsigned soff) {
-#ifndef WN_BC_ABL_NOREQ
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory", WN_BC_RES);
-#endif
-}
-// A vector-memory operation that only keeps the count of a boundary's group (4 bytes per lane of a hot line).  Its destination
-// is one of the fixed registers too: the word arrives long after the statement, in a register the compiler would otherwise
-// have given to something else by then (the first version of this kernel computed one wrong tile per layer that way).
-WN_DEV void bc_dummy(unsigned voff, rsrc_t rs) {
-#ifndef WN_BC_ABL_NOREQ
-    asm volatile("buffer_load_dword a159, %0, %1, 0 offen" ::"v"(voff), "s"(rs) : "memory", WN_BC_RES);
+#if !defined(WN_BC_ABL_NOREQ) && !defined(WN_BC_ABL_NOSTORE)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" WN_BC_ST_AUX ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory", WN_BC_RES);
 #endif
 }
 // Every load of register set SET has landed once at most N younger vector-memory operations are outstanding; from here on the
@@ -291,10 +327,8 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
 
     // ---- wave-uniform addressing ---------------------------------------------------------------------------------------
     const size_t strmBytes = C::waveStreamFrags(L) * 1024;                 // one stream of the blob; cyclic per sample
-    const unsigned totBytes = (unsigned)strmBytes;
     const char* const wbase = (const char*)p.wblob;
     const char* const wMine = wbase + (size_t)w * strmBytes;               // this wave copies its own stream
-    const rsrc_t rsW = make_rsrc(wMine);
     const unsigned ringMineLds =
         (unsigned)(size_t)(__attribute__((address_space(3))) char*)ringLds + (unsigned)w * (unsigned)(NSLOT * 1024);
     const size_t ringTile = (size_t)p.ringSlots * KF_R * 1024;
@@ -323,8 +357,15 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
     // ---- conditioning / dilated-tap register sets (two, by layer parity): fixed accumulator registers (see above) --------
     static_assert(BTW * NCD <= 8 && BTW * KF_R <= 4, "fixed register map of the two sets");
     // load jj of a request into set SET: jj < BTW*NCD conditioning fragment (row at `row`), else tap fragment (ring slot `slot`)
-    auto req_one = [&](auto SETT, auto JJ, const char* row, const unsigned slot) {
+    auto req_one = [&](auto SETT, auto JJ, const char* row, unsigned slot) {
         constexpr int SET = decltype(SETT)::value, jj = decltype(JJ)::value;
+#ifdef WN_BC_ABL_HOT      // (timing experiment: every request reads the same, L2-resident rows)
+        row = (const char*)p.cond + (size_t)tileW * kCondTile;
+        slot = 0;
+#endif
+#ifdef WN_BC_ABL_NOLOADS  // (timing experiment: no conditioning / tap loads, ring stores kept)
+        return;
+#endif
         if constexpr (jj < BTW * NCD) {
             constexpr int b = jj / NCD, c = jj % NCD;
             bc_load_fixed<bc_cd_reg(SET, jj)>(lane16 + (unsigned)(c & 3) * 1024u, make_rsrc(row), (unsigned)(b * kCondTile + (c & ~3) * 1024));
@@ -334,28 +375,26 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
                                              slot * (unsigned)(KF_R * 1024) + (unsigned)b * ringTileB + (unsigned)(k & ~3) * 1024u);
         }
     };
-    // the E operations of a boundary's group: loads [J0, J0 + E) of a request where they exist, dummy loads otherwise
+    // the loads of a boundary's group: [J0, J0 + E) of a request, where they exist (BCfg::opsAt is the count)
     auto group_ops = [&](auto SETT, auto J0, const char* row, const unsigned slot) {
         static_for<E>([&](auto I) {
             constexpr int jj = decltype(J0)::value + decltype(I)::value;
             if constexpr (jj >= 0 && jj < B::REQ_LOADS) req_one(SETT, std::integral_constant<int, jj>{}, row, slot);
-            else bc_dummy(lane16 >> 2, rsW);
         });
     };
     using SET0 = std::integral_constant<int, 0>;
     using SET1 = std::integral_constant<int, 1>;
 
     // ---- the weight ring: first turn -----------------------------------------------------------------------------------
-    // positions [0, NSLOT) of every stream; dmaOff = byte position (in a stream) of the next chunk to copy
-    unsigned dmaOff = 0;
-#pragma unroll
-    for (int c = 0; c < B::NCH; c++) {
-        bc_dma<CH>(ringMineLds + (unsigned)(c * CH * 1024), lane16, wMine + dmaOff);
-        dmaOff += CH * 1024;
-    }
+    // positions [0, NSLOT) of every stream; dmaV = lane * 16 + byte position (in the stream) of the chunk being copied
+    unsigned dmaV = lane16;
+    static_for<B::NCH>([&](auto CI) {
+        static_for<CH>([&](auto J) { bc_dma_piece<decltype(CI)::value * CH, decltype(J)::value>(ringMineLds, dmaV, wMine); });
+        dmaV += CH * 1024;
+    });
     // every position consumed refills the slot CH positions back with the stream NSLOT positions on (consume): the launch's
     // first CH positions have no finished chunk behind them -- they rewrite the last CH slots with what these hold already
-    dmaOff = (unsigned)((NSLOT - CH) * 1024);
+    dmaV = lane16 + (unsigned)((NSLOT - CH) * 1024);
     // the fragment FIFO: the NQ fragments of RAP consecutive positions, read RAP positions ahead of the MFMAs
     frag fifo[RAP][NQ];
     auto fifo_fill = [&](auto POS) {       // position POS (relative to a multiple of NSLOT) into its FIFO slot
@@ -440,22 +479,20 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
     // CU's vector-memory path takes a few hundred cycles to accept, every wave stalled on its issue (measured: 30 of 125 k cycles
     // per sample).  Its pieces follow one per position of the next chunk's consumption (consume); the counts stay what they were:
     // behind the last piece of a chunk come the E operations of the boundary that ends the chunk after, then whole groups.
-    auto boundary = [&](auto&& ops) {
-#ifndef WN_BC_ABL_NOBAR
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(B::kWaitBoundary) : "memory", WN_BC_RES);
+    // (W = BCfg::waitAt of the boundary: the vector-memory operations issued behind the last of those copies)
+    auto boundary = [&](auto W, auto&& ops) {
+#if defined(WN_BC_ABL_NOWAITB)   // (timing experiment: the barrier without the wait for the copies)
+        asm volatile("s_barrier" ::"n"(decltype(W)::value) : "memory", WN_BC_RES);
+#elif !defined(WN_BC_ABL_NOBAR)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(decltype(W)::value) : "memory", WN_BC_RES);
 #endif
         ops();
     };
-    // piece of ring slot SLOT: the stream NSLOT positions on (dmaOff walks the stream one position per call)
-    auto dma_piece = [&](auto SLOT) {
-        bc_dma1(ringMineLds + (unsigned)(decltype(SLOT)::value * 1024), lane16, wMine + dmaOff);
-        dmaOff += 1024;
-        if (dmaOff == totBytes) dmaOff = 0;
-    };
-    // consume stream positions [P0, P0 + N) (relative to a multiple of FLW): use(f, a[]) gets the NQ fragments of position
-    // P0 + f; grp(boundary position) supplies the E other operations of every chunk boundary inside
-    auto consume = [&](auto P0T, auto NT, auto&& use, auto&& grp) {
-        constexpr int P0 = decltype(P0T)::value, N = decltype(NT)::value;
+    // consume stream positions [P0, P0 + N) of part PART of the sample's stream (BCfg::PART_*; positions relative to a multiple
+    // of FLW, in the head to the head's start): use(f, a[]) gets the NQ fragments of position P0 + f; grp(boundary position)
+    // issues the loads of every chunk boundary inside (BCfg::opsAt says how many)
+    auto consume = [&](auto PARTT, auto P0T, auto NT, auto&& use, auto&& grp) {
+        constexpr int PART = decltype(PARTT)::value, P0 = decltype(P0T)::value, N = decltype(NT)::value;
         static_for<N>([&](auto FI) {
             constexpr int pos = P0 + decltype(FI)::value;
             frag a[NQ];
@@ -463,16 +500,28 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
             for (int q = 0; q < NQ; q++) a[q] = fifo[pos % RAP][q];
             use(FI, a);
             fifo_fill(std::integral_constant<int, pos + RAP>{});
-            // the slot CH positions back belongs to the chunk that everybody finished before the latest boundary
-            dma_piece(std::integral_constant<int, (pos + NSLOT - CH) % NSLOT>{});
+            // the slot CH positions back belongs to the chunk that everybody finished before the latest boundary: it receives
+            // the stream NSLOT positions on, piece by piece
+            constexpr int jp = pos % CH;
+            bc_dma_piece<(pos - jp + NSLOT - CH) % NSLOT, jp>(ringMineLds, dmaV, wMine);
+            if constexpr (jp == CH - 1) {
+                // the next chunk's place in the stream, which is cyclic per sample: the copies run NSLOT - CH positions ahead
+                // of the consumption and reach the end of the stream inside the head
+                if constexpr (PART == B::PART_HEAD && pos + 1 + NSLOT - CH == B::FHWP) dmaV = lane16;
+                else dmaV += CH * 1024;
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((pos + 1) % CH == 0) {
-                boundary([&]() { grp(std::integral_constant<int, pos + 1>{}); });
+                boundary(std::integral_constant<int, B::waitAt(PART, pos + 1)>{}, [&]() { grp(std::integral_constant<int, pos + 1>{}); });
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
     };
-    auto dummies = [&](auto) { group_ops(SET0{}, std::integral_constant<int, B::REQ_LOADS>{}, condReq, 0u); };
+    auto no_loads = [&](auto) {};
+    using PL0 = std::integral_constant<int, B::PART_L0>;
+    using PGEN = std::integral_constant<int, B::PART_GEN>;
+    using PTAIL = std::integral_constant<int, B::PART_TAIL>;
+    using PHEAD = std::integral_constant<int, B::PART_HEAD>;
 
     // skip accumulators: the accumulator file, touched by their MFMAs only (fp16: inline assembly, see the header)
     floatx4 skip[BTW][ST];
@@ -574,12 +623,13 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
             // group of boundary position BP: the first groups of a generic layer's part carry its request; layer 0's carry the
             // loads from REQ_HEAD on (the previous sample's head issued the first REQ_HEAD)
             auto grp = [&](auto BP) {
-                constexpr int gi = SK ? decltype(BP)::value / CH - B::P_CUR / CH - 1 : decltype(BP)::value / CH - 1;
+                constexpr int gi = SK ? (decltype(BP)::value - B::BP0_GEN) / CH : decltype(BP)::value / CH - 1;
                 group_ops(setC, std::integral_constant<int, SK ? gi * E : REQ_HEAD + gi * E>{}, condReq, slot2);
             };
+            using PART = std::conditional_t<SK, PGEN, PL0>;
 
             // -- current tap on top of bias + conditioning + dilated tap --
-            consume(std::integral_constant<int, PC>{}, std::integral_constant<int, FW_GATE>{},
+            consume(PART{}, std::integral_constant<int, PC>{}, std::integral_constant<int, FW_GATE>{},
                     [&](auto FI, const frag (&a)[NQ]) {
                         constexpr int f = decltype(FI)::value;
 #pragma unroll
@@ -621,7 +671,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 if constexpr (SK) {
-                    consume(std::integral_constant<int, PS>{}, std::integral_constant<int, FW_SKIP>{},
+                    consume(PART{}, std::integral_constant<int, PS>{}, std::integral_constant<int, FW_SKIP>{},
                             [&](auto FI, const frag (&a)[NQ]) {
                                 constexpr int f = decltype(FI)::value;
                                 static_for<NQ * BTW>([&](auto MI) {
@@ -659,7 +709,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
 #pragma unroll
                 for (int b = 0; b < BTW; b++) xa[b][i] = bq + x[b][i];
             }
-            consume(std::integral_constant<int, PR>{}, std::integral_constant<int, FW_RES>{},
+            consume(PART{}, std::integral_constant<int, PR>{}, std::integral_constant<int, FW_RES>{},
                     [&](auto FI, const frag (&a)[NQ]) {
                         constexpr int f = decltype(FI)::value;
 #pragma unroll
@@ -675,7 +725,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
             floatx4 cdN[8], xpN[4];
             bc_wait_set<SETN, B::kWaitUse>(cdN, xpN);
             bias_cond(blN, cdN);
-            consume(std::integral_constant<int, PP>{}, std::integral_constant<int, FW_GATE>{},
+            consume(PART{}, std::integral_constant<int, PP>{}, std::integral_constant<int, FW_GATE>{},
                     [&](auto FI, const frag (&a)[NQ]) {
                         constexpr int f = decltype(FI)::value;
                         if (havePrevN) {       // (before the start the tap is zero, reference :287)
@@ -745,9 +795,8 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
         const unsigned slotH = (unsigned)(dS2.off + ((t + 1) & (dS2.d - 1)));
         auto grpHead = [&](auto BP) {
             if constexpr (decltype(BP)::value == B::FHWP && REQ_HEAD > 0) group_ops(SET0{}, IC0{}, condReq, slotH);
-            else dummies(BP);
         };
-        consume(std::integral_constant<int, B::P_CUR>{}, std::integral_constant<int, FW_SKIP>{},
+        consume(PTAIL{}, std::integral_constant<int, B::P_CUR>{}, std::integral_constant<int, FW_SKIP>{},
                 [&](auto FI, const frag (&a)[NQ]) {
                     constexpr int f = decltype(FI)::value;
                     constexpr int G = STW >= 4 ? 4 : STW, kf = (f / G) % KF_R, sl = (f / (G * KF_R)) * G + f % G;
@@ -756,7 +805,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
 #pragma unroll
                         for (int b = 0; b < BTW; b++) mma_skip(skip[b][q + NQ * sl], a[q], hbB[b][kf]);
                 },
-                dummies);
+                no_loads);
         settle_skip();
         floatx4 zs[BTW][AT];
         {
@@ -778,7 +827,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
 #pragma unroll
                 for (int b = 0; b < BTW; b++) zs[b][i] = bq;
             }
-            consume(IC0{}, std::integral_constant<int, B::FW_ZS>{},
+            consume(PHEAD{}, IC0{}, std::integral_constant<int, B::FW_ZS>{},
                     [&](auto FI, const frag (&a)[NQ]) {
                         constexpr int f = decltype(FI)::value;
 #pragma unroll
@@ -789,7 +838,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
                         }
                     },
                     grpHead);
-            consume(std::integral_constant<int, B::FW_ZS>{}, std::integral_constant<int, C::PAD1>{}, [&](auto, const frag (&)[NQ]) {}, grpHead);
+            consume(PHEAD{}, std::integral_constant<int, B::FW_ZS>{}, std::integral_constant<int, C::PAD1>{}, [&](auto, const frag (&)[NQ]) {}, grpHead);
         }
         floatx4 za[BTW][AT];
         {
@@ -809,7 +858,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
 #pragma unroll
                 for (int b = 0; b < BTW; b++) za[b][i] = bq;
             }
-            consume(std::integral_constant<int, C::O_ZA>{}, std::integral_constant<int, B::FW_ZA>{},
+            consume(PHEAD{}, std::integral_constant<int, C::O_ZA>{}, std::integral_constant<int, B::FW_ZA>{},
                     [&](auto FI, const frag (&a)[NQ]) {
                         constexpr int f = decltype(FI)::value;
 #pragma unroll
@@ -820,7 +869,7 @@ __global__ __launch_bounds__((BCfg<F16, R, S, A, BTW>::THREADS), 1) void wavenet
                         }
                     },
                     grpHead);
-            consume(std::integral_constant<int, C::O_ZA + B::FW_ZA>{}, std::integral_constant<int, C::PAD2>{}, [&](auto, const frag (&)[NQ]) {},
+            consume(PHEAD{}, std::integral_constant<int, C::O_ZA + B::FW_ZA>{}, std::integral_constant<int, C::PAD2>{}, [&](auto, const frag (&)[NQ]) {},
                     grpHead);
         }
 

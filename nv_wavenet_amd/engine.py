@@ -30,10 +30,9 @@ class Org:
     WG3 = 4         # three tiles per workgroup (fp16, R <= 64; else two)
     CHAIN = 5       # wn::wavenet_chain: multi-CU, weights resident, fewest CUs
     CHAIN1 = 6      # wn::wavenet_chain, one layer per CU
-    BCAST = 7       # wn::wavenet_bcast: whole tiles per wave, weights broadcast through an LDS ring; 1 or 2 tiles per wave by batch
+    BCAST = 7       # wn::wavenet_bcast: one whole tile per wave, weights broadcast through an LDS ring
     BCAST1 = 8
-    BCAST2 = 9
-    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6, "bcast": 7, "bcast1": 8, "bcast2": 9}
+    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6, "bcast": 7, "bcast1": 8}
 
 
 def supported_configs():

@@ -21,13 +21,13 @@ def _bspb(B):
 # the kernel organisations: wavenet_wg with one / two / three tiles of 16 utterances per workgroup (wn_kernels.hpp; the engine
 # picks by batch size: beyond one / two tiles per CU) and the multi-CU chain with resident weights (wn_chain.hpp; "chain": as
 # many layers per CU as stay resident, "chain1": one layer per CU)
-# ... and wn::wavenet_bcast (wn_bcast.hpp, round 4): every wave runs the whole network for its own tiles, the weights broadcast
-# through an LDS ring ("bcast": one tile per wave, "bcast2": two -- fp16, launches without the activation dump)
+# ... and wn::wavenet_bcast (wn_bcast.hpp, round 4): every wave runs the whole network for its own tile, the weights broadcast
+# through an LDS ring ("bcast": four tiles per workgroup)
 MODES = ["wg", "wg2", "chain", "bcast"]
 ALL_MODES = MODES + ["chain1"]
-FP16_MODES = ["wg", "wg2", "wg3", "chain", "chain1", "bcast", "bcast2"]
+FP16_MODES = ["wg", "wg2", "wg3", "chain", "chain1", "bcast"]
 KERNEL_OF = {"wg": "wavenet_wg<", "wg2": "wavenet_wg<", "wg3": "wavenet_wg<", "chain": "wavenet_chain<", "chain1": "wavenet_chain<",
-             "bcast": "wavenet_bcast<", "bcast2": "wavenet_bcast<"}
+             "bcast": "wavenet_bcast<"}
 
 
 def _bcast_shape(shape, precision=16):
@@ -43,11 +43,9 @@ def _check_mode(e, mode, shape, precision=32):
     if mode in ("chain", "chain1") and shape.R >= 256:
         assert "wavenet_wg<" in info, info
         return
-    if mode in ("bcast", "bcast2") and not _bcast_shape(shape, precision):
+    if mode == "bcast" and not _bcast_shape(shape, precision):
         assert "wavenet_wg<" in info, info
         return
-    if mode == "bcast2" and precision == 16:
-        assert "BTW=2" in info, info
     assert KERNEL_OF[mode] in info, (mode, info)
     if mode == "wg2" and shape.R < 128:   # (two tiles of R >= 128 do not fit the LDS of one workgroup: one tile runs)
         assert "BT=2" in info, info
@@ -238,7 +236,7 @@ def test_fp16_engine_against_the_oracle_o1(name, mode, record_property):
 @pytest.mark.parametrize("name", ["C2", "C3", "C4"])
 def test_fp16_organisations_are_bit_identical_o1(name):
     """Same arithmetic in the same order in every organisation: the free-running fp16 samples are IDENTICAL."""
-    ys = {m: _fp16_checked_run(name, m)[1] for m in (["wg", "chain"] if name == "C4" else ["wg", "wg3", "chain", "bcast", "bcast2"])}
+    ys = {m: _fp16_checked_run(name, m)[1] for m in (["wg", "chain"] if name == "C4" else ["wg", "wg3", "chain", "bcast"])}
     first = ys.pop("wg")
     for m, y in ys.items():
         assert np.array_equal(first, y), "wavenet_wg and %s disagree in fp16" % m
@@ -440,7 +438,7 @@ def test_conditioning_consumed_in_place(mode, precision):
 
 
 @pytest.mark.parametrize("mode,precision", [("wg", 32), ("chain", 32), ("bcast", 32), ("wg", 16), ("wg2", 16), ("wg3", 16), ("chain", 16),
-                                            ("bcast", 16), ("bcast2", 16)])
+                                            ("bcast", 16)])
 def test_conditioning_produced_in_fragment_order(mode, precision):
     """Round 3: conditioning the caller PRODUCES in the engine's fragment order (setConditioningPacked; a model folds the
     channel permutation and the gate's pre-scale into its conditioning convolution, nv_wavenet.py: get_cond_input(layout=
@@ -623,16 +621,16 @@ def test_benchmarked_path_exactly(tiles_per_cu):
         y48 = sequence(3 * s.B, util.MODE_ORG["wg"])
         assert np.array_equal(y48[:s.B], y16)
         assert not np.array_equal(y48[s.B:2 * s.B], y16), "utterances 16.. drew utterance 0..'s selectors"
-        for mode in ("wg3", "bcast", "bcast2"):
+        for mode in ("wg3", "bcast"):
             assert np.array_equal(sequence(3 * s.B, util.MODE_ORG[mode]), y48), "%s differs from the one-tile kernel on the benchmarked sequence" % mode
         return
     # the headline batch (the engine's own choice: three tiles per workgroup, the kernel bench.py asserts): its first 1024
     # utterances against the one-tile kernel run on 1024 utterances, whose first 16 are the oracle-held ones of the other case
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     B = tiles_per_cu * 16 * ncu
-    # (four / eight tiles per CU: beyond the real-time capacity the engine runs wn::wavenet_bcast with one / two tiles per wave on
-    #  every CU -- the launch shapes of bench.py's `oversubscribed` entry, and the full-load stress of its LDS ring protocol)
-    y = sequence(B, 0, bench.HEADLINE_KERNELS.get(tiles_per_cu, "wn::wavenet_bcast<fp16,64,256,256,BTW=%d,EMBLDS=1,DUMP=0>" % (tiles_per_cu // 4)))
+    # (four tiles per CU: one round of wn::wavenet_bcast workgroups on every CU -- the full-load stress of its LDS ring protocol;
+    #  eight: whole rounds of three-tile wavenet_wg workgroups again -- the launch shapes of bench.py's `oversubscribed` entry)
+    y = sequence(B, 0, "wn::wavenet_bcast<fp16,64,256,256,BTW=1,EMBLDS=1,DUMP=0>" if tiles_per_cu == 4 else bench.HEADLINE_KERNELS[3])
     y1k = sequence(1024, util.MODE_ORG["wg"])
     assert np.array_equal(y[:1024], y1k), "the headline batch differs from the one-tile kernel on the benchmarked sequence"
     assert np.array_equal(y1k[:s.B], sequence(s.B, util.MODE_ORG["wg"]))
@@ -978,9 +976,9 @@ def test_full_chip_batches_by_replication_fp16(B, impl):
     tiles = (B + 15) // 16
     info = e.kernelInfo(B, False)
     assert "DUMP=0" in info and "fp16" in info, info
-    # ... and beyond three tiles per CU the throughput organisation, wn::wavenet_bcast (two tiles per wave beyond four per CU)
-    bc = impl == 0 and tiles > 3 * ncu
-    want = ("BTW=2" if tiles > 4 * ncu else "BTW=1") if bc else "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
+    # ... and between three and four tiles per CU one round of wn::wavenet_bcast workgroups (beyond: rounds of three-tile workgroups)
+    bc = impl == 0 and 3 * ncu < tiles <= 4 * ncu
+    want = "BTW=1" if bc else "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
     assert want in info and ("wavenet_bcast<" in info) == bc, (info, ncu)
     y = np.full((B, s.N), -1, dtype=np.int32)
     assert e.run(s.N, B, y, 1, False)
