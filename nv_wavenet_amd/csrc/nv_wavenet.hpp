@@ -241,23 +241,35 @@ protected:
     // The single-workgroup organisation: one, two or -- fp16, R <= 64 -- three tiles per workgroup (split over the 4 SIMDs
     // of a CU) by batch size, see wgTiles(); beyond three tiles per CU the launch simply has more workgroups than CUs.
     int singleOrg(int) const { return NVW_ORG_WG; }
-    // Per-sample time models (microseconds) of the organisations that can run `tiles` tiles, from the
-    // shape: weight bytes per sample W, layers L, CUs.  Constants measured on MI355X:
-    // a CU streams 58 B/clk of weights at ~2.1 GHz beside ~0.45 us of dependent chain per layer; a chain
-    // stage costs one ~1.1 us hand-off plus ~0.5 us per layer with resident weights.
+    // Per-sample time models (microseconds) of the organisations that can run `tiles` tiles, from the shape: weight bytes per
+    // sample W, layers L, CUs.  Every constant is a measurement on MI355X, kept with its source:
+    struct OrgTimes {
+        // the multi-CU chain only competes at batches of a few tiles, where the GPU holds its full shader clock
+        // (profiles/r04_clock_wg_sweep.json: 2.39 GHz up to 192 busy CUs, 2.0 with all 256)
+        static constexpr double kClockMHz = 2390.0;
+        static constexpr double kStreamBytesPerClk = 58.0;   // weight stream L2 -> registers of one CU (scripts/ubench/stream.hip)
+        static constexpr double kStreamLayerUs = 0.25;       // dependent chain per layer beside the stream (one tile)
+        static constexpr double kHeadUs = 4.0;               // head GEMMs + softmax + embedding, either organisation
+        static constexpr double kChainHopUs = 1.1;           // one stage hand-off (hop 0.55 + entry / exit)
+        static constexpr double kChainLayerUs(int r) { return r >= 128 ? 0.55 : 0.4; }   // resident-weight layer of a stage
+        // one round of workgroups on every CU, C3 fp16, steady state (profiles/r04_*): three-tile wavenet_wg 36.5 us per
+        // sample, wavenet_bcast (four tiles per workgroup) 54 us: bcast wins exactly where wavenet_wg needs a second round and
+        // bcast does not
+        static constexpr double kWg3RoundUs = 36.5, kBcastRoundUs = 54.0;
+    };
     int pickOrganisation(int tiles) const {
-        // beyond what wavenet_wg serves in one round of workgroups (three tiles per CU) and up to four tiles per CU, one round of
-        // wavenet_bcast (four tiles per workgroup) beats two rounds of wavenet_wg (measured, C3 fp16 at 16 384 utterances: 54 us
-        // against 2 x 36.5 us per sample); beyond that, whole rounds of three-tile workgroups win again (kOrgTimes)
         if constexpr (F16 && BC1) {
-            if (tiles > 3 * m_numCUs && tiles <= 4 * m_numCUs && bcastFits()) return NVW_ORG_BCAST;
+            const int cus = m_numCUs;
+            const double tWg = OrgTimes::kWg3RoundUs * ((tiles + 3 * cus - 1) / (3 * cus));
+            const double tBc = OrgTimes::kBcastRoundUs * ((tiles + 4 * cus - 1) / (4 * cus));
+            if (tiles > 3 * cus && tBc < 0.9 * tWg && bcastFits()) return NVW_ORG_BCAST;      // (a near tie stays with wavenet_wg)
         }
         const int single = singleOrg(tiles);
         const int lpc = chainLpcMax(m_numLayers);
         if (!chainFits(lpc, tiles)) return single;
         const double wBytes = sizeof(elem) * ((double)m_numLayers * (5.0 * R * R + (double)S * R) + (double)A * S + (double)A * A);
-        const double tStream = wBytes / (58.0 * 2100.0) + 0.25 * m_numLayers + 4.0;    // us: L1 weight stream + chain + head
-        const double tChain = 1.1 * chainStagesFor(m_numLayers, lpc) + (R >= 128 ? 0.55 : 0.4) * m_numLayers + 4.0;
+        const double tStream = wBytes / (OrgTimes::kStreamBytesPerClk * OrgTimes::kClockMHz) + OrgTimes::kStreamLayerUs * m_numLayers + OrgTimes::kHeadUs;
+        const double tChain = OrgTimes::kChainHopUs * chainStagesFor(m_numLayers, lpc) + OrgTimes::kChainLayerUs(R) * m_numLayers + OrgTimes::kHeadUs;
         return tChain < tStream ? NVW_ORG_CHAIN : single;
     }
     void resolveOrganisation(int requested) {

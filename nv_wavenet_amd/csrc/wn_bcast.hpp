@@ -194,12 +194,6 @@ template <int SLOT0, int J> WN_DEV void bc_dma_piece(unsigned ringMine, unsigned
 #endif
 }
 // one 16-byte-per-lane load into the fixed accumulator quad a[REG:REG+3], streaming policy; valid only behind a bc_wait_set
-#ifndef WN_BC_LD_AUX
-#define WN_BC_LD_AUX " nt"
-#endif
-#ifndef WN_BC_ST_AUX
-#define WN_BC_ST_AUX " nt"
-#endif
 template <int REG> WN_DEV void bc_load_fixed(unsigned voff, rsrc_t rs, unsigned soff) {
     static_assert(REG >= kBcCdReg && REG + 3 <= 255 && REG % 4 == 0, "fixed register map");
 #ifndef WN_BC_ABL_NOREQ

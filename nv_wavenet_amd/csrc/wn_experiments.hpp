@@ -1,0 +1,64 @@
+// wn_experiments.hpp -- every compile-time switch of the kernels that is NOT part of the product, in one place.
+//
+// A default build defines none of the ablations and takes every tunable at the value below; the shipped library is built that
+// way (csrc/Makefile passes no -DWN_*).  A/B builds for timing experiments go through scripts/build_variant.sh <name> "<-D...>"
+// and are loaded with NVW_LIB=<that library>; the measurements behind the values are in LABNOTES.md.
+#pragma once
+
+// ---- tunables (each settled by measurement; change one with -D for an A/B build) ---------------------------------------------
+#ifndef WN_PFMAX
+#define WN_PFMAX 12          // wavenet_wg: largest depth of the per-wave weight prefetch ring (the divisor of a layer's stream <= this: 9)
+#endif
+#ifndef WN_HEADREGS
+#define WN_HEADREGS 128      // wavenet_wg, one tile per workgroup: accumulator registers the resident A x A head matrix may take
+#endif
+#ifndef WN_HEADREGS2
+#define WN_HEADREGS2 128     // ... two tiles per workgroup
+#endif
+#ifndef WN_HEADREGS3
+#define WN_HEADREGS3 0       // ... three tiles per workgroup: the whole head is streamed
+#endif
+#ifndef WN_TAKE_G
+#define WN_TAKE_G 1          // wavenet_wg: weight fragments waited for together (take_group); > 1 measured slower
+#endif
+#ifndef WN_REQ_AT
+#define WN_REQ_AT 6          // wavenet_wg: eighths of the skip GEMM behind which taps and conditioning of layer l+2 are requested
+#endif
+// cache-policy bits of the buffer instructions (0 = default, 2 = nt / streaming, 16 = sc1)
+#ifndef WN_W_AUX
+#define WN_W_AUX 0           // the weight stream: must stay in L2 (nt: +20 % per sample)
+#endif
+#ifndef WN_RING_LD_AUX
+#define WN_RING_LD_AUX 2     // dilated taps
+#endif
+#ifndef WN_RING_ST_AUX
+#define WN_RING_ST_AUX 2     // ring stores
+#endif
+#ifndef WN_COND_AUX
+#define WN_COND_AUX 2        // packed conditioning
+#endif
+#ifndef WN_RAW_AUX
+#define WN_RAW_AUX 0         // conditioning read in place from the caller's [N][L][B][2R] tensor
+#endif
+#ifndef WN_BC_LD_AUX
+#define WN_BC_LD_AUX " nt"   // wavenet_bcast: conditioning / tap loads (instruction modifier text)
+#endif
+#ifndef WN_BC_ST_AUX
+#define WN_BC_ST_AUX " nt"   // wavenet_bcast: ring stores
+#endif
+
+// ---- ablations: TIMING ONLY -- the samples are wrong with any of them (none is defined in a product build) -------------------
+//   wavenet_wg   WN_ABL_NOACT          gate without transcendentals        WN_ABL_NOWEIGHTLOAD  no weight refills
+//                WN_ABL_NOXP           no dilated-tap loads                WN_ABL_NOCOND        no conditioning loads
+//                WN_ABL_HOTLOADS / WN_ABL_HOTTAPS / WN_ABL_HOTCOND         taps / conditioning always from the same, L2-resident rows
+//                WN_ABL_NOTAPGEMM      the tap GEMM's MFMAs not issued     WN_ABL_NOBARRIER     no workgroup barriers
+//                WN_ABL_NOHEADRES      no resident head matrix
+//   wavenet_bcast WN_BC_ABL_NODMA      no weight copies                    WN_BC_ABL_NOBAR      no chunk barriers / waits
+//                WN_BC_ABL_NOWAITB     barriers without the wait for the copies
+//                WN_BC_ABL_NOFIFO      no fragment reads from LDS          WN_BC_ABL_NOREQ      no conditioning / tap loads, no ring stores
+//                WN_BC_ABL_NOLOADS / WN_BC_ABL_NOSTORE                     only the loads / only the stores of those removed
+//                WN_BC_ABL_HOT         conditioning / taps always from the same, L2-resident rows
+//                WN_BC_WAITU=<n>       another count for the conditioning wait
+// ---- probes (results stay right) ------------------------------------------------------------------------------------------
+//   WN_TIMING        wavenet_wg: per-phase shader-clock sums of wave 0 into Params::p (scripts/quick_phase.py)
+//   WN_CHAIN_TIMING  wavenet_chain: wall-clock stamps per stage (scripts/chain_phase.py)

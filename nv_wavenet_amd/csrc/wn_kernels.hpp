@@ -60,6 +60,8 @@
 
 #include <type_traits>
 
+#include "wn_experiments.hpp"
+
 namespace wn {
 
 #define WN_DEV __device__ __forceinline__
@@ -137,9 +139,6 @@ struct Cfg {
     // them in place) depth 9: 19.6 / 24.2 / 33.4 and depth 18 (a whole layer): 21.0 / 26.2 / 37.7 at batch
     // 16 / 4096 / 8192: a ring that does not divide the streamed head (32 fragments) is rotated once per sample,
     // and every such rotation -- like every register copy the compiler places on a loop edge -- drains the queue.
-#ifndef WN_PFMAX
-#define WN_PFMAX 12
-#endif
     static constexpr int PF = pick_pf(FLW, WN_PFMAX);
     static_assert(FLW % PF == 0 && PF <= FW_ZS, "prefetch ring must divide the layer stream");
     // The head's weights (FHW fragments per wave) stay RESIDENT in registers for the whole launch
@@ -152,15 +151,6 @@ struct Cfg {
 #else
     // Register budget of the resident head.  Measured (C3 fp16): keeping Wzs resident as well (256
     // registers) buys nothing over Wza alone (128) and costs spills once the layer loop is unrolled.
-#ifndef WN_HEADREGS
-#define WN_HEADREGS 128
-#endif
-#ifndef WN_HEADREGS2
-#define WN_HEADREGS2 128     // two tiles per workgroup
-#endif
-#ifndef WN_HEADREGS3
-#define WN_HEADREGS3 0       // three tiles per workgroup: the whole head is streamed
-#endif
     static constexpr int HR = !F16 ? 0
                               : BT == 1 ? (FW_ZA * 4 <= WN_HEADREGS ? FW_ZA : 0)
                               : BT == 2 ? (FW_ZA * 4 <= WN_HEADREGS2 ? FW_ZA : 0)
@@ -381,21 +371,10 @@ WN_DEV void gate_stage(float a0, float a1, float b0, float b1, floatx2& ea, floa
     } else {
         if constexpr (ST == 0) ea = floatx2{__builtin_amdgcn_exp2f(a0), __builtin_amdgcn_exp2f(a1)};
         if constexpr (ST == 1) eb = floatx2{__builtin_amdgcn_exp2f(b0), __builtin_amdgcn_exp2f(b1)};
-#ifdef WN_GATE_PK
-        if constexpr (ST == 2) {
-            const floatx2 s = ea + 1.0f;        // (v_pk_add_f32)
-            ra = floatx2{fast_rcp(s[0]), fast_rcp(s[1])};
-        }
-        if constexpr (ST == 3) {
-            const floatx2 s = eb + 1.0f;
-            rb = floatx2{fast_rcp(s[0]), fast_rcp(s[1])};
-        }
-#else
         // scalar adds: a packed-f32 VALU instruction issued beside MFMAs costs more than the two plain ones it replaces
         // (MI355X_MICROARCH.md: +22..26 clk per pair)
         if constexpr (ST == 2) ra = floatx2{fast_rcp(ea[0] + 1.0f), fast_rcp(ea[1] + 1.0f)};
         if constexpr (ST == 3) rb = floatx2{fast_rcp(eb[0] + 1.0f), fast_rcp(eb[1] + 1.0f)};
-#endif
         if constexpr (ST == 4) h = floatx2{gate_finish(ra[0], rb[0]), gate_finish(ra[1], rb[1])};
     }
 #endif
@@ -499,16 +478,11 @@ WN_DEV typename Prec<F16>::frag take(WStream<F16, PF, PIN>& ws, int idx, const c
     const char* src = (WRAP > 0 && nidx >= WRAP) ? wrapBase + (size_t)(nidx - WRAP) * 1024 : base + (size_t)nidx * 1024;
     if (nidx >= rtWrapAt) src += rtWrapDelta;
     ws.buf[idx % PF] = *(const frag*)(src + laneOff);
-#ifndef WN_FREE_REFILL
     // The refill stays where the ring discipline puts it.  Left to the scheduler the loads get
     // clustered and re-ordered, and now and then a fragment that is needed next ends up among the
     // youngest requests (a near-drain of the queue): pinned, C3 fp16 runs 39.0 instead of 42.0 us per
     // sample with two tiles per workgroup at batch 8192.
-#ifndef WN_TAKE_SCHED_MASK
-#define WN_TAKE_SCHED_MASK 0
-#endif
-    __builtin_amdgcn_sched_barrier(WN_TAKE_SCHED_MASK);
-#endif
+    __builtin_amdgcn_sched_barrier(0);
 #else
     (void)nidx; (void)base; (void)wrapBase; (void)laneOff; (void)rtWrapAt; (void)rtWrapDelta;
 #endif
@@ -573,9 +547,6 @@ WN_DEV void gemm_ldsb(WStream<F16, PF, PIN>& ws, int pos0, const char* cur, cons
 // waits for its youngest fragment before its first MFMA, which shortens the 9-fragment lookahead by G-1, and at
 // ~700 clk per L2 load the stream has no slack for that.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
-#ifndef WN_TAKE_G
-#define WN_TAKE_G 1          // fragments taken (waited for) together: see take_group
-#endif
 __host__ __device__ constexpr int take_g(int g, int pf) {     // group size: divides g, at most WN_TAKE_G and the ring
     int t = g < WN_TAKE_G ? g : WN_TAKE_G;
     t = t < pf ? t : pf;
@@ -584,9 +555,6 @@ __host__ __device__ constexpr int take_g(int g, int pf) {     // group size: div
 }
 WN_DEV rsrc_t make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, -1, 0x00020000); }
 // AUX: cache policy bits of the instruction (0 = default, 2 = non-temporal / streaming)
-#ifndef WN_W_AUX
-#define WN_W_AUX 0           // cache policy of the weight stream (experiments: 16 = sc1, L1 bypass; 2 = nt)
-#endif
 template <typename FRAG, int AUX = 0> WN_DEV FRAG buf_load(rsrc_t rs, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(FRAG, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX));
 }
@@ -1005,19 +973,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     // cache policy of the in-place reads: a (sample, layer) row of an utterance is 2R elements, of which a wave takes two
     // quads per gate tile -- the four waves of the workgroup share every cache line of it
     // (default policy rather than streaming: 44.7 instead of 46.8 us per sample at 12 288 utterances from an fp16 tensor)
-#ifndef WN_RAW_AUX
-#define WN_RAW_AUX 0
-#endif
     // cache-policy bits of the ring loads / ring stores / packed-conditioning loads (2 = nt, streaming; experiments: 0, 1 = sc0, 16 = sc1)
-#ifndef WN_RING_LD_AUX
-#define WN_RING_LD_AUX 2
-#endif
-#ifndef WN_RING_ST_AUX
-#define WN_RING_ST_AUX 2
-#endif
-#ifndef WN_COND_AUX
-#define WN_COND_AUX 2
-#endif
     const size_t rawRow = (size_t)p.maxBatch * (2 * R) * RAWE;
     unsigned rawOff[BT];
 #pragma unroll
@@ -1310,9 +1266,6 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         // from here that is behind the rest of the gate, both exchanges and the residual GEMM, the longest
                         // such stretch of a layer (issued right behind the current-tap GEMM instead: 34.2 instead of
                         // 31.7 us per sample at 8192 utterances, 41.9 instead of 39.7 at 12 288).
-#ifndef WN_REQ_AT
-#define WN_REQ_AT 6          // eighths of the skip GEMM behind which taps and conditioning are requested
-#endif
                         if constexpr (gi == (STW * KF_R / G) * WN_REQ_AT / 8) {
                             prefetch(t, l + 2, dl2, xpC, cdC);
                             __builtin_amdgcn_sched_barrier(0);
