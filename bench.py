@@ -740,7 +740,7 @@ def main():
         passes = (tiles + bt - 1) // bt
         traffic, lds_counter, traffic_file = None, None, None
         # HBM and LDS bytes per launch from the PMC passes of the latest profiled round (profiles/traffic_rNN.json, written
-        # by scripts/make_profiles_r3.py from rocprofv3 counters); only valid for the launch shape it was measured on
+        # by scripts/make_profiles_r*.py from rocprofv3 counters); only valid for the launch shape it was measured on
         import glob
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
             try:
@@ -765,6 +765,12 @@ def main():
             roofline["shader_cycles_per_sample"] = kern_ms * 1e-3 / N * clock_ghz * 1e9
             roofline["frac_at_measured_clock"] = roofline["frac"] * 2.4 / clock_ghz
         roofline["hbm"]["frac"] = roofline["hbm"]["achieved"] / HBM_PEAK_GBS
+        # ... and with the dilation ring, which this design keeps in HBM (read x[t-d], write x[t]: 2 x 2R bytes per layer, utterance and
+        # sample): the bytes the kernel actually asks of the memory system (what `traffic` measures), and the roof it is nearest to
+        ring_bytes = 2 * 2 * HEAD.R * HEAD.L
+        roofline["hbm_with_ring"] = dict(achieved=units * (HEAD.hbm_bytes + ring_bytes) / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                         bytes_per_utterance_sample=HEAD.hbm_bytes + ring_bytes)
+        roofline["hbm_with_ring"]["frac"] = roofline["hbm_with_ring"]["achieved"] / HBM_PEAK_GBS
         if not chain_mode:                                      # (the chain reads no weights after its prologue)
             roofline["l2_weight_stream"] = dict(achieved=passes * N * HEAD.weight_bytes / (kern_ms * 1e-3) / 1e9,
                                                 peak=L2_PEAK_GBS, unit="GB/s")

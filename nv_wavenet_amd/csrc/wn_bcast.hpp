@@ -1,37 +1,40 @@
-// wn_bcast.hpp -- wn::wavenet_bcast: the throughput organisation of the engine (round 4).
+// wn_bcast.hpp -- wn::wavenet_bcast: one round of workgroups for batches between three and four tiles per CU (round 4).
 //
 // wavenet_wg (wn_kernels.hpp) splits the ROWS of every GEMM over the four waves of a workgroup, so the waves exchange h and x
-// through LDS twice per layer: two barriers and two LDS round trips on the dependent chain of every layer, and a quarter of
-// the machine's time parked in s_waitcnt / s_barrier (profiles/r04_pmc_issue.txt).  This organisation splits the UTTERANCES:
+// through LDS twice per layer and a workgroup holds at most three tiles of 16 utterances.  This organisation splits the
+// UTTERANCES, four tiles per workgroup:
 //
-//   * every wave runs the WHOLE network for its own BTW tiles of 16 utterances.  The MFMA result tile (lane (g,j): rows
-//     4g..4g+3 of utterance j) is the next GEMM's B fragment once converted (wn_kernels.hpp, layout notes), so h and x never
-//     leave the wave's registers: no activation exchange, no barrier on the dependent chain, and the four waves of a workgroup
-//     depend on each other for nothing but the weights;
+//   * every wave runs the WHOLE network for its own tile of 16 utterances.  The MFMA result tile (lane (g,j): rows 4g..4g+3 of
+//     utterance j) is the next GEMM's B fragment once converted (wn_kernels.hpp, layout notes), so h and x never leave the
+//     wave's registers: no activation exchange, and the four waves of a workgroup depend on each other for nothing but the
+//     weights;
 //   * the weights are streamed ONCE per workgroup and sample: the four per-wave streams of the packed blob (the very streams
-//     wavenet_wg reads, same order) are copied global -> LDS by LDS-DMA (buffer_load ... lds: no register round trip, 1 KiB
-//     per wave instruction), each wave copying its own stream, into a ring of NSLOT stream positions per stream; every wave
-//     then reads every fragment with ds_read_b128 (LDS delivers 256 B/clk per CU against the 58 B/clk of the L1 -> register
-//     path) two positions ahead of the MFMAs that use it.  NSLOT divides the layer and the head part of the stream, so the
-//     LDS address of every fragment is a compile-time constant;
+//     wavenet_wg reads, same order) are copied global -> LDS by LDS-DMA (global_load_lds: no register round trip, 1 KiB per wave
+//     instruction), each wave copying its own stream, into a ring of NSLOT stream positions per stream; every wave then reads
+//     every fragment with ds_read_b128 two positions ahead of the MFMAs that use it.  NSLOT divides the layer and the head part
+//     of the stream, so the LDS address of every fragment is a compile-time constant;
 //   * the ring is recycled in CHUNKS of CH positions behind one bare s_barrier per chunk: before barrier k a wave makes sure
 //     its own copies of chunk k+2 have landed (a counted s_waitcnt vmcnt), after it the chunk just consumed is dead for
-//     everybody and is refilled with the stream NSLOT positions on;
+//     everybody and is refilled, one copy per consumed position, with the stream NSLOT positions on;
 //   * the compiler orders a DS read behind EVERY pending LDS-DMA of the wave (it cannot tell ring slots apart), which would
-//     drain the copy queue in front of each fragment read, so the copies are issued from inline assembly and waited for by
-//     hand.  VMEM returns in order per wave and s_waitcnt takes an immediate, so the hand-placed counts must be exact: every
-//     chunk boundary issues exactly CH copies + E other vector-memory operations (the conditioning / dilated-tap loads of the
-//     layer after next, issued from assembly as well -- or dummy loads where a boundary has nothing to request), which makes
-//     the counts two constants (kWaitBoundary, kWaitUse).  Operations the counts do not know (ring stores, the compiler's own
+//     drain the copy queue in front of each fragment read, so the copies -- and the conditioning / dilated-tap loads of the
+//     layer after next, up to E per chunk boundary -- are issued from inline assembly and waited for by hand.  VMEM returns in
+//     order per wave and s_waitcnt takes an immediate, so every count is a compile-time function of what the boundaries in
+//     front of it issued (BCfg::opsAt / waitAt / kWaitUse; tests/test_bcast_waits_cpu.py replays a wave's queue against these
+//     tables: never too large, exact in the steady state).  Operations the counts do not know (ring stores, the compiler's own
 //     few global accesses per sample) are always YOUNGER than what is waited for, which only makes a wait stricter;
 //   * the running skip sum lives in the accumulator file and is touched by nothing but its MFMAs (inline assembly: the fp16
-//     builds select VGPR-destination MFMAs globally, -amdgpu-mfma-vgpr-form), which leaves the architectural VGPRs to the
-//     gate / residual working set of two tiles;
+//     builds select VGPR-destination MFMAs globally, -amdgpu-mfma-vgpr-form);
 //   * schedule of a layer (= the order of the stream): cur GEMM | gate arithmetic with the previous layer's skip GEMM issued
 //     MFMA by MFMA between its stages | residual GEMM | bias + conditioning + dilated-tap GEMM of the next layer.
 //
 // Arithmetic, summation order per accumulator, rounding points and the layouts of ring / conditioning / history are those of
 // wavenet_wg: samples are bit-identical and the device state is interchangeable between the organisations.
+// Where its time goes (one workgroup, C3 fp16, 112 k clk per sample; LABNOTES.md round 4): 44 k is the network itself; the
+// rest is the price of the weight copies (18 k), of the chunk barriers (24 k: skew between four independent waves), of the
+// HBM loads and ring stores sharing the CU's vector-memory path with the copies (18 k) and of the fragment reads (4 k).
+// (BTW, tiles per wave, is kept as a parameter of the code; only BTW = 1 is instantiated: a two-tile variant spilled 130
+//  registers and was no faster than rounds of three-tile wavenet_wg workgroups -- removed.)
 #pragma once
 
 #include "wn_kernels.hpp"
@@ -134,7 +137,7 @@ struct BCfg {
     }
     static constexpr bool SUPPORTED =
         R == 64 && NQ == 4 && A <= 256 && S <= 256 && BTW == 1 && NSLOT >= 8 && NCH >= 4 && CH >= RAP && CH <= 4 && P_CUR % RAP == 0 &&
-        FLW % RAP == 0 && FHWP % RAP == 0 && REQ_HEAD <= E && REQ_GROUPS <= GROUPS_L && P_PREV % CH == 0 &&
+        FLW % RAP == 0 && FHWP % RAP == 0 && (REQ_HEAD == 0 || REQ_HEAD == E) && REQ_GROUPS <= GROUPS_L && P_PREV % CH == 0 &&
         P0_PREV % CH == 0 && FLW % CH == 0 && FHWP >= (NCH - 3) * CH && GROUPS_L0 >= NCH - 3 && tailsOrdered() &&
         (NCH - 3) * (CH + E) <= 63 && kWaitUse <= 63 && FW_SKIP + FHWP + P0_PREV >= kWaitUse;
     // gate tile of fragment-local slot `it` of stream q (Cfg: a wave's rows come in (tanh tile, sigmoid tile) pairs)
