@@ -495,11 +495,20 @@ def main():
                     help="c5: BASELINE configs[4], global batch 64 sharded over the ranks (8 x 8 on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip reference_definition / end_to_end / oversubscribed")
+    ap.add_argument("--extras-budget", type=float, default=240.0,
+                    help="seconds of wall clock the entries beside the headline may take together; what does not fit is reported as skipped")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
     ap.add_argument("--selftest-dist", action="store_true", help="launcher / rendezvous / gather plumbing only (no GPU)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seed", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    t_main = time.perf_counter()
+
+    def note(msg):                               # progress on stderr (stdout carries the one JSON line)
+        print("[bench %6.1f s] %s" % (time.perf_counter() - t_main, msg), file=sys.stderr, flush=True)
+
+    def extras_left():
+        return args.extras_budget - (time.perf_counter() - t_main)
     if args.cpu_worker:
         dt, _ = cpu_run_once(make_weights(), args.cpu_worker, seed=5 + args.cpu_seed)
         print(json.dumps({"cpu_worker_seconds": dt}))
@@ -579,9 +588,15 @@ def main():
     # ---- beside the headline (rank 0, one GPU): the reference's own measurement on C2 / C3 / C4, the
     #      throughput organisation, and the real-time batch with conditioning streamed per chunk ----
     refdef, thr, e2e = None, None, None
+    skipped = []
+    note("workload: %d utterances per GPU, %d samples per step" % (B, N))
     if extras and rank == 0:
         refdef = {}
         for sh in (C2, C3, C4):
+            if extras_left() < 30:
+                skipped.append("reference_definition.%s" % sh.name)
+                continue
+            note("reference_definition %s" % sh.name)
             refdef[sh.name] = {"single_workgroup": reference_definition_khz(sh, 1),
                                "multi_cu_chain": reference_definition_khz(sh, 3),
                                "auto": reference_definition_khz(sh, 0)}
@@ -601,12 +616,17 @@ def main():
         # time; reported at four and at six tiles per CU (= two full rounds)
         thr = {"definition": "batches beyond the real-time capacity: more utterances per GPU at a lower rate per utterance "
                              "(steady state, samples 640..1151; the engine's own choice of organisation)", "points": []}
+        note("oversubscribed")
         for bt_ in (bt, 96 * ncu):
+            if extras_left() < 20:
+                skipped.append("oversubscribed.%d" % bt_)
+                continue
             khz_t, info_t = measure_steady_khz(w, bt_, 256)
             thr["points"].append({"batch_per_gpu": bt_, "khz_per_utterance": khz_t, "samples_per_sec_per_gpu": bt_ * khz_t * 1e3,
                                   "kernel": info_t.split(" ")[0], "real_time": bool(khz_t >= REALTIME_KHZ)})
-        best_t = max(thr["points"], key=lambda q: q["samples_per_sec_per_gpu"])
-        thr.update({k: best_t[k] for k in ("batch_per_gpu", "khz_per_utterance", "samples_per_sec_per_gpu", "kernel", "real_time")})
+        if thr["points"]:
+            best_t = max(thr["points"], key=lambda q: q["samples_per_sec_per_gpu"])
+            thr.update({k: best_t[k] for k in ("batch_per_gpu", "khz_per_utterance", "samples_per_sec_per_gpu", "kernel", "real_time")})
         e2e = {"definition": "conditioning fp32 [N][L][B][2R] in HBM, packed per chunk of 256 samples on a second stream "
                              "behind the generation of the previous chunk; Philox selectors; samples left in HBM",
                "sweep_khz": {}}
@@ -614,6 +634,10 @@ def main():
         for cand in sorted(set([B // 4, B * 3 // 8, B // 2, B * 3 // 4, B] + [c for c in (16 * ncu, 24 * ncu, 32 * ncu) if c <= B]),
                            reverse=True):
             cand = max(16, cand // 64 * 64)
+            if extras_left() < 20:
+                skipped.append("end_to_end.%d" % cand)
+                break
+            note("end_to_end %d" % cand)
             k = end_to_end_khz(w, cand)
             e2e["sweep_khz"][str(cand)] = k
             if k >= REALTIME_KHZ:
@@ -630,6 +654,10 @@ def main():
         best_wp = None
         for cand in sorted(set([B, B * 3 // 4, B // 2, B * 3 // 8, B // 4]), reverse=True):
             cand = max(16, cand // 64 * 64)
+            if extras_left() < 20:
+                skipped.append("end_to_end.with_producer.%d" % cand)
+                break
+            note("with_producer %d" % cand)
             try:
                 k = with_producer_khz(w, cand)
             except RuntimeError as ex:          # (out of memory in the producer's workspaces at the largest batch)
@@ -648,7 +676,12 @@ def main():
         e2e["in_place"] = {}
         for name, dt in (("fragment_order", "fragments"), ("fp16_tensor", torch.float16), ("fp32_tensor", torch.float32)):
             ip_sweep = {}
+            k_ip, info_ip = 0.0, ""
             for cand in [B] + [c for c in (32 * ncu, 16 * ncu) if c < B]:
+                if extras_left() < 20:
+                    skipped.append("end_to_end.in_place.%s.%d" % (name, cand))
+                    break
+                note("in_place %s %d" % (name, cand))
                 k_ip, info_ip = measure_steady_khz(w, cand, in_place=dt)
                 ip_sweep[str(cand)] = k_ip
                 if k_ip >= REALTIME_KHZ:
@@ -665,6 +698,7 @@ def main():
     # ---- the timed workload: every step generates samples STEADY_FROM .. STEADY_FROM+N-1 (all dilated taps live, all rings
     #      wrapped, conditioning rows of exactly those samples) for every utterance (re-run per step on the rings the previous step left:
     #      timing only, see config.workload)
+    note("timed steps")
     e, NTOT, _keep = steady_engine(w, B, N, 100 + rank)
     e.setClockProbe(True)                       # workgroup 0 of every launch records shader / wall clock counters
     kinfo = e.kernelInfo(B, False)
@@ -807,11 +841,14 @@ def main():
             "reference_definition": refdef,
             "end_to_end": e2e,
             "oversubscribed": thr,
+            "extras_skipped_for_time": skipped,
             "distinct_samples_in_last_step": hist,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
+            note("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(w)
+        note("done")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -162,8 +162,24 @@ def pack_cond_input(cond_nlbc, precision, tiles):
     return _fragments_from_ordered(x, tiles, dtype)
 
 
+def _upsample_trimmed_gemm(features, weight, bias, stride):
+    """ConvTranspose1d(kernel = m * stride, stride) followed by the trimming of its (kernel - stride) tail, as ONE matrix product
+    and m shifted adds: out[b][f*stride + r][co] = bias[co] + sum_j sum_ci features[b][ci][f - j] * weight[ci][co][j*stride + r].
+    The library convolution compiles its kernels at first use on a machine without a kernel cache (MIOpen: a quarter of an hour
+    of host time for bench.py's shapes on a fresh GPU box); a matrix product does not."""
+    B, Ci, Fr = features.shape
+    Co, K = weight.size(1), weight.size(2)
+    m = K // stride
+    y = torch.matmul(features.transpose(1, 2), weight.reshape(Ci, Co * K)).view(B, Fr, Co, m, stride)     # [B][f][co][j][r]
+    out = y[:, :, :, 0, :].clone()
+    for j in range(1, min(m, Fr)):
+        out[:, j:] += y[:, :Fr - j, :, j, :]
+    # channels last, [B][samples][co]: the 1x1 convolution behind it is then ONE matrix product over all (utterance, sample) rows
+    return out.permute(0, 1, 3, 2).reshape(B, Fr * stride, Co) + bias[None, None, :]
+
+
 def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, cond_weight, cond_bias, n_layers,
-                   layout="CBLN", dtype=None, precision=16, tiles=None, out=None):
+                   layout="CBLN", dtype=None, precision=16, tiles=None, out=None, via_gemm=None):
     """WaveNet.get_cond_input (pytorch/wavenet.py:190-202) as a function of the module's tensors,
     run wherever `features` lives (the GPU): ConvTranspose1d upsampling, trimming of the
     (kernel - stride) transposed-convolution tail, the 1x1 `cond_layers` convolution.
@@ -175,12 +191,21 @@ def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, co
     layout "packed" (round 3) emits the engine's own FRAGMENT order for an engine of `precision` bits whose condTiles() is
     `tiles` (NVWaveNetEngine.cond_tiles): the channel permutation and the gate's pre-scale are folded into the weights of the
     1x1 convolution -- its output channels simply come out in fragment order, scaled -- so the only extra work against "NLBC"
-    is none: one permuting copy either way, and the generation kernels then run their packed path on the result as it is."""
+    is none: one permuting copy either way, and the generation kernels then run their packed path on the result as it is.
+    via_gemm: None = on the GPU the two convolutions run as matrix products (_upsample_trimmed_gemm; same sums in another order),
+    on the CPU as the torch convolutions the reference's modules call (bit-identical to them); True / False force either."""
     import torch.nn.functional as F
-    x = F.conv_transpose1d(features, upsample_weight, upsample_bias, stride=upsample_stride)
-    cutoff = upsample_weight.size(2) - upsample_stride
-    if cutoff > 0:
-        x = x[:, :, :-cutoff]
+    gemm = features.is_cuda if via_gemm is None else via_gemm
+    if gemm and upsample_weight.size(2) % upsample_stride == 0:
+        x = _upsample_trimmed_gemm(features, upsample_weight, upsample_bias, upsample_stride)         # [B][N][n_cond]
+        # [B][N][n_cond] x [n_cond][channels] -> the [B][channels][N] the code below expects, as a view of the channels-last product
+        conv1x1 = lambda t, w, b: torch.matmul(t, w.reshape(w.size(0), w.size(1)).t()).add_(b).transpose(1, 2)
+    else:
+        x = F.conv_transpose1d(features, upsample_weight, upsample_bias, stride=upsample_stride)
+        cutoff = upsample_weight.size(2) - upsample_stride
+        if cutoff > 0:
+            x = x[:, :, :-cutoff]
+        conv1x1 = F.conv1d
     if layout == "packed":
         assert tiles is not None, "layout='packed' needs the engine's condTiles()"
         C2 = cond_weight.size(0) // n_layers
@@ -189,7 +214,7 @@ def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, co
         sc = torch.tensor(scale, dtype=cond_weight.dtype, device=cond_weight.device)
         w = cond_weight.view(n_layers, C2, cond_weight.size(1), 1).index_select(1, idx) * sc[None, :, None, None]
         b = cond_bias.view(n_layers, C2).index_select(1, idx) * sc[None, :]
-        x = F.conv1d(x, w.reshape(n_layers * C2, cond_weight.size(1), 1), b.reshape(-1))        # [B][L * 2R][N]
+        x = conv1x1(x, w.reshape(n_layers * C2, cond_weight.size(1), 1), b.reshape(-1))        # [B][L * 2R][N]
         if out is not None:
             # straight into N samples of an existing packed buffer: [tile][j][l][wave*fragment][g][e][n] -> [n][l][tile][wf][g][j][e]
             EPL = 8 if precision == 16 else 4
@@ -198,7 +223,7 @@ def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, co
             return out
         x = x.view(x.size(0), n_layers, C2, x.size(2)).permute(3, 1, 0, 2)            # [N][L][B][2R], fragment channel order
         return _fragments_from_ordered(x, tiles, torch.float16 if precision == 16 else torch.float32)
-    x = F.conv1d(x, cond_weight, cond_bias)
+    x = conv1x1(x, cond_weight, cond_bias)
     x = x.view(x.size(0), n_layers, -1, x.size(2))          # [B][L][2R][N]
     if layout == "CBLN":
         x = x.permute(2, 0, 1, 3)

@@ -38,8 +38,12 @@ def pmc_of(doc, sub):
     return out
 
 
+def demangle(name):
+    return subprocess.run(["c++filt", name[:-3] if name.endswith(".kd") else name], capture_output=True, text=True).stdout.strip() or name
+
+
 def stats_table(doc):
-    rows = sorted(doc["kernels"].items(), key=lambda kv: -kv[1]["total_ns"])
+    rows = sorted(((demangle(k), v) for k, v in doc["kernels"].items()), key=lambda kv: -kv[1]["total_ns"])
     tot = sum(v["total_ns"] for _, v in rows)
     out = ["%-100s %6s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct")]
     for k, v in rows[:12]:
@@ -51,6 +55,7 @@ def stats_table(doc):
 
 def trace_file(tag, sub, B, cmd, what, out):
     line = json.load(open(f"{G}/{tag}_bench_line.json"))
+    NSTEP = line["config"]["samples_per_step"]          # (16 384 utterances time 64-sample steps: bench.py keeps the packed conditioning under 60 GB)
     doc = load(f"{tag}_kt")
     name, k = kernel_of(doc, sub)
     dur = k["durations_ns"]
@@ -69,7 +74,7 @@ def trace_file(tag, sub, B, cmd, what, out):
         f.write("# MFMA roofline from the profiler's average: %.1f TFLOP/s = %.4f of 2500 dense fp16 (minimum launch: %.4f)\n" %
                 (B * NSTEP * FLOP / avg / 1e12, B * NSTEP * FLOP / avg / PEAK, B * NSTEP * FLOP / (min(timed) * 1e-9) / PEAK))
         f.write(stats_table(doc))
-    return line, len(timed), avg
+    return line, len(timed), avg, NSTEP
 
 
 def issue_lines(c, f, waves_per_cu=4):
@@ -84,18 +89,27 @@ def issue_lines(c, f, waves_per_cu=4):
                     ("SQ_ACTIVE_INST_SCA", "  scalar issue"), ("SQ_ACTIVE_INST_MISC", "  other issue")):
         if k in c:
             f.write("#   %-22s %5.1f %%   %s\n" % (k, 100.0 * c[k] / wc, what))
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CU_CYCLES" in c and c["SQ_BUSY_CU_CYCLES"]:
-        f.write("#   matrix pipe busy: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES = %.1f %%\n" % (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CU_CYCLES"]))
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"]:
-        f.write("#   SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES = %.3f (per-SE busy cycles; 4 SIMDs per CU count into the numerator)\n" %
-                (c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"]))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        # units, from the counters themselves: SQ_VALU_MFMA_BUSY_CYCLES = 16 x SQ_INSTS_MFMA exactly (clocks: a 16x16x32 f16 MFMA holds the
+        # pipe for 16), SQ_WAVE_CYCLES x 4 = the clocks the waves were resident (quad-cycles, MI355X_MICROARCH.md), GRBM_GUI_ACTIVE =
+        # clocks per XCD
+        f.write("#   matrix pipe busy: SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_WAVE_CYCLES) = %.1f %% of the clocks a wave (= a SIMD) was resident\n" %
+                (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * wc)))
+        if "GRBM_GUI_ACTIVE" in c and "SQ_INSTS_MFMA" in c:
+            f.write("#     (check: SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA = %.2f clk per MFMA)\n" % (c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_INSTS_MFMA"]))
+        if "GRBM_GUI_ACTIVE" in c:
+            gpu_clk = c["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs
+            f.write("#   ... / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) = %.1f %% of every SIMD clock of the launches (the MFMA roofline at the clock granted)\n" %
+                    (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gpu_clk * 1024)))
+    if "SQ_ACTIVE_INST_ANY" in c and "SQ_INSTS_VALU" in c:
+        pass
 
 
 # ---- the headline kernel at 12 288 utterances ------------------------------------------------------------------------------
 B = 12288
 CMD = f"python bench.py --batch {B} --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
-KERN = "wavenet_wg<"
-line, nl, avg = trace_file("prof4", KERN, B, CMD,
+KERN = "wavenet_wgI"          # (this rocprofv3 stores mangled names)
+line, nl, avg, NSTEP = trace_file("prof4", KERN, B, CMD,
                            "wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0,RAW=0>: three tiles of 16 utterances per workgroup, 256 workgroups",
                            f"{P}/r04_kernel_trace_stats_wg_b12288.txt")
 c = {}
@@ -147,23 +161,23 @@ json.dump(line, open(f"{P}/r04_bench_line_under_rocprof_b12288.json", "w"))
 # ---- wavenet_bcast at 16 384 utterances ------------------------------------------------------------------------------------
 B2 = 16384
 CMD2 = f"python bench.py --batch {B2} --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
-K2 = "wavenet_bcast<"
-line2, nl2, avg2 = trace_file("prof4_bc", K2, B2, CMD2,
+K2 = "wavenet_bcastI"
+line2, nl2, avg2, NS2 = trace_file("prof4_bc", K2, B2, CMD2,
                               "wn::wavenet_bcast<fp16,64,256,256,BTW=1,EMBLDS=1,DUMP=0>: every wave one tile (four per workgroup), 256 workgroups; "
                               "not real time (the engine's choice between three and four tiles per CU)",
                               f"{P}/r04_kernel_trace_stats_bcast_b16384.txt")
 c2 = {}
 for d in ("ldsbw", "issue"):
     c2.update(pmc_of(load(f"prof4_bc_{d}"), K2))
-st2 = STEADY + NSTEP * nl2
+st2 = STEADY + NS2 * nl2
 wg2 = st2 * (B2 // 64)
 with open(f"{P}/r04_pmc_bcast_b16384.txt", "w") as f:
     f.write(f"# round 4, wn::wavenet_bcast<fp16,64,256,256,BTW=1,EMBLDS=1,DUMP=0> at 16 384 utterances, steady state ({CMD2})\n")
     lds2 = (c2["SQ_INSTS_LDS_LOAD_BANDWIDTH"] + c2["SQ_INSTS_LDS_STORE_BANDWIDTH"]) * 64 / wg2
     k2 = line2["roofline"]["kernel_ms"] * 1e-3
     f.write("# LDS (rocprof-reported): %.2f MB per workgroup-sample (every wave reads every weight fragment: 4 x 1.7 MB + the copies' 1.7 MB arrive by DMA);\n" % (lds2 / 1e6))
-    f.write("#   per timed launch %.1f GB; at kernel_ms %.3f: %.1f TB/s = %.1f %% of the 157 TB/s LDS peak\n" %
-            (lds2 * (B2 // 64) * NSTEP / 1e9, k2 * 1e3, lds2 * (B2 // 64) * NSTEP / k2 / 1e12, 100 * lds2 * (B2 // 64) * NSTEP / k2 / 157.3e12))
+    f.write("#   per timed launch (%d samples) %.1f GB; at kernel_ms %.3f: %.1f TB/s = %.1f %% of the 157 TB/s LDS peak\n" %
+            (NS2, lds2 * (B2 // 64) * NS2 / 1e9, k2 * 1e3, lds2 * (B2 // 64) * NS2 / k2 / 1e12, 100 * lds2 * (B2 // 64) * NS2 / k2 / 157.3e12))
     f.write("#   bank-conflict cycles / LDS-active cycles = %.1f %%\n" % (100 * c2["SQ_LDS_BANK_CONFLICT"] / c2["SQ_LDS_IDX_ACTIVE"]))
     f.write("# VALU : MFMA = %.2f, MFMA per wave and tile-sample = %.0f\n" % (c2["SQ_INSTS_VALU"] / c2["SQ_INSTS_MFMA"], c2["SQ_INSTS_MFMA"] / (wg2 * 4)))
     issue_lines(c2, f)
