@@ -111,6 +111,39 @@ def test_get_cond_input_matches_torch_modules():
     assert got2.is_contiguous() and torch.equal(got2, column_major(x.contiguous()))
 
 
+@pytest.mark.parametrize("n_cond,R,L,B,frames,win,stride", [(8, 4, 3, 2, 5, 12, 4), (80, 64, 20, 32, 1, 1024, 256), (16, 8, 2, 4, 7, 32, 8),
+                                                            (8, 4, 3, 2, 2, 16, 4), (8, 4, 2, 3, 6, 10, 4)])
+def test_get_cond_input_as_matrix_products_equals_the_convolutions(n_cond, R, L, B, frames, win, stride):
+    """On the GPU get_cond_input runs its two convolutions as matrix products (the library convolutions compile their kernels at
+    first use on a machine without a cache: bench.py's default run did not finish for that).  Same sums in another order: every
+    layout must agree with the torch convolutions to fp32 rounding, the fragment-order output (fp16) to one unit in the last
+    place, also when it is written into an existing packed buffer; a kernel that is no multiple of the stride falls back."""
+    import torch
+    from nv_wavenet_amd.nv_wavenet import get_cond_input
+    torch.manual_seed(1)
+    up_w, up_b = torch.randn(n_cond, n_cond, win) * 0.1, torch.randn(n_cond)
+    cw, cb = torch.randn(2 * R * L, n_cond, 1) * 0.2, torch.randn(2 * R * L)
+    f = torch.randn(B, n_cond, frames)
+    for lay in ("NLBC", "CBLN"):
+        a = get_cond_input(f, up_w, up_b, stride, cw, cb, L, layout=lay, via_gemm=False)
+        b = get_cond_input(f, up_w, up_b, stride, cw, cb, L, layout=lay, via_gemm=True)
+        assert a.shape == b.shape == ((frames * stride, L, B, 2 * R) if lay == "NLBC" else (2 * R, B, L, frames * stride))
+        assert torch.allclose(a, b, rtol=0, atol=2e-5 * float(a.abs().max())), float((a - b).abs().max())
+    if R == 64:
+        tiles = B // 16
+        a = get_cond_input(f, up_w, up_b, stride, cw, cb, L, layout="packed", precision=16, tiles=tiles, via_gemm=False)
+        b = get_cond_input(f, up_w, up_b, stride, cw, cb, L, layout="packed", precision=16, tiles=tiles, via_gemm=True)
+        assert a.dtype == b.dtype == torch.float16 and a.shape == b.shape
+        ulp = float(a.float().abs().max()) * 2.0 ** -10
+        assert float((a.float() - b.float()).abs().max()) <= ulp
+        n = frames * stride
+        o1 = torch.zeros(n + 1, L, tiles, 2 * R // 32, 4, 16, 8, dtype=torch.float16)
+        o2 = torch.zeros_like(o1)
+        get_cond_input(f, up_w, up_b, stride, cw, cb, L, layout="packed", precision=16, tiles=tiles, out=o1[:n], via_gemm=False)
+        get_cond_input(f, up_w, up_b, stride, cw, cb, L, layout="packed", precision=16, tiles=tiles, out=o2[:n], via_gemm=True)
+        assert float((o1.float() - o2.float()).abs().max()) <= ulp and torch.equal(o1[:n], a[:n]) and not o1[n].any()
+
+
 def test_reference_style_host_program_compiles_against_nv_wavenet_hpp():
     """a host translation unit written the way the reference's nv_wavenet_test.cu /
     pytorch/wavenet_infer.cu use nvWavenetInfer -- every member, the reference's defaults, a lambda
