@@ -660,7 +660,7 @@ def main():
             note("with_producer %d" % cand)
             try:
                 k = with_producer_khz(w, cand)
-            except RuntimeError as ex:          # (out of memory in the producer's workspaces at the largest batch)
+            except Exception as ex:             # (e.g. out of memory in the producer's workspaces at the largest batch: an entry beside the headline must not take the run down)
                 wp["sweep_khz"][str(cand)] = "failed: %s" % str(ex)[:80]
                 torch.cuda.empty_cache()
                 continue

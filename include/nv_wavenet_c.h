@@ -103,6 +103,17 @@ void nvw_set_conditioning_packed(nvw_engine* e, const void* frags, int num_sampl
  * the other preconditions of the path) to generate more samples than were handed over here. */
 int nvw_set_conditioning_packed_n(nvw_engine* e, const void* frags, int num_samples, size_t elems);
 int nvw_cond_tiles(nvw_engine* e);
+/* The PRODUCER of such a buffer for fp16 engines (role of the model's `cond_layers` 1x1 convolution, pytorch/wavenet.py:190-202, with
+ * the engine's channel order and gate pre-scale folded into its weights): one MFMA kernel from the upsampled features straight
+ * into fragment order, no intermediate tensor, no permuting copy.  All pointers are device memory:
+ *   x      [tiles*16][num_samples][32*kfrags] fp16: upsampled features, channels last, zero-padded to whole 32-feature fragments
+ *   wfrag  [num_layers][nwf][2][kfrags][64][8] fp16 and bias [num_layers][nwf*32] fp32: the convolution's weights and bias as
+ *          nv_wavenet_amd/nv_wavenet.py:cond_producer_weights arranges them (nwf = 2R/32 fragments per tile)
+ *   out    [num_samples][num_layers][tiles][nwf][64][8] fp16: `num_samples` samples of the buffer handed to
+ *          nvw_set_conditioning_packed_n (tiles = nvw_cond_tiles(e))
+ * Asynchronous on `stream`; returns 0 when the arguments are out of range (1 <= kfrags <= 4) or the launch failed. */
+int nvw_produce_conditioning_f16(const void* x, const void* wfrag, const float* bias, void* out, int tiles, int num_samples,
+                                 int num_layers, int kfrags, int nwf, void* stream);
 /* the selector half of nvw_set_inputs ([num_samples][batch] uniform draws, host or device); conditioning and history untouched */
 void nvw_set_selectors(nvw_engine* e, float* output_selectors, int num_samples);
 /* Multi-CU (wavenet_chain) launches need all their workgroups resident at once; when other work holds CUs a launch gives up

@@ -41,6 +41,7 @@ SIGNATURES = {
     "nvw_set_conditioning_packed": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_set_conditioning_packed_n": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_size_t]),
     "nvw_cond_tiles": (C.c_int, [C.c_void_p]),
+    "nvw_produce_conditioning_f16": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "nvw_set_selectors": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_chain_status": (C.c_uint, [C.c_void_p]),
     "nvw_chain_fallbacks": (C.c_uint, [C.c_void_p]),

@@ -162,24 +162,82 @@ def pack_cond_input(cond_nlbc, precision, tiles):
     return _fragments_from_ordered(x, tiles, dtype)
 
 
-def _upsample_trimmed_gemm(features, weight, bias, stride):
-    """ConvTranspose1d(kernel = m * stride, stride) followed by the trimming of its (kernel - stride) tail, as ONE matrix product
-    and m shifted adds: out[b][f*stride + r][co] = bias[co] + sum_j sum_ci features[b][ci][f - j] * weight[ci][co][j*stride + r].
+def cond_producer_weights(cond_weight, cond_bias, n_layers, precision=16):
+    """The `cond_layers` 1x1 convolution (weight [2R*L][n_cond][1], bias [2R*L]) as the operands of the engine's fused producer
+    (csrc/cond_producer.hip, nvw_produce_conditioning_f16): rows in the engine's fragment-position order with the gate's pre-scale
+    folded in (cond_fragment_order), cut into MFMA A fragments.  Returns (wfrag fp16 [L][NWF][2][KF][64][8], bias fp32 [L][NWF*32],
+    KF, NWF): fragment wf of a tile holds positions wf*32 .. wf*32+31; its row tile tt has row m = 4g + r at position
+    (wf*4 + g)*8 + tt*4 + r, so that lane (g, j) of the two result tiles holds the 8 halves the packed layout gives it."""
+    assert precision == 16, "the fused producer serves the fp16 engine"
+    C2 = cond_weight.size(0) // n_layers
+    n_cond = cond_weight.size(1)
+    perm, scale = cond_fragment_order(C2 // 2, precision)
+    dev = cond_weight.device
+    idx = torch.tensor(perm, device=dev)
+    sc = torch.tensor(scale, dtype=torch.float32, device=dev)
+    w = cond_weight.reshape(n_layers, C2, n_cond).float().index_select(1, idx) * sc[None, :, None]          # rows = positions
+    b = (cond_bias.reshape(n_layers, C2).float().index_select(1, idx) * sc[None, :]).contiguous()
+    KF = (n_cond + 31) // 32
+    NWF = C2 // 32
+    w = torch.nn.functional.pad(w, (0, KF * 32 - n_cond))                                                     # [L][C2][32 KF]
+    m = torch.arange(16, device=dev)
+    rows = ((torch.arange(NWF, device=dev)[:, None, None] * 4 + (m // 4)[None, None, :]) * 8
+            + torch.arange(2, device=dev)[None, :, None] * 4 + (m % 4)[None, None, :])                          # [wf][tt][i] -> position
+    wg = w[:, rows.reshape(-1), :].reshape(n_layers, NWF, 2, 16, KF, 4, 8)                                     # [l][wf][tt][i][kf][ga][e]
+    wfrag = wg.permute(0, 1, 2, 4, 5, 3, 6).contiguous().to(torch.float16)                                     # [l][wf][tt][kf][ga][i][e]
+    return wfrag.reshape(n_layers, NWF, 2, KF, 64, 8), b, KF, NWF
+
+
+def produce_cond_packed(x_channels_last, wfrag, bias, out, tiles):
+    """x [tiles*16][N][32 KF] fp16 (upsampled features, channels last, zero-padded) -> N samples of a packed conditioning buffer
+    (out: [N][L][tiles][NWF][4][16][8] fp16, contiguous; e.g. a slice of what setConditioningPacked was given) on torch's
+    current stream, by the engine's own kernel."""
+    from ._lib import lib
+    L, NWF, _, KF = wfrag.shape[:4]
+    N = x_channels_last.size(1)
+    assert x_channels_last.is_cuda and x_channels_last.dtype == torch.float16 and x_channels_last.is_contiguous()
+    assert x_channels_last.shape == (tiles * 16, N, 32 * KF), (tuple(x_channels_last.shape), tiles, KF)
+    assert out.is_cuda and out.dtype == torch.float16 and out.is_contiguous() and out.numel() == N * L * tiles * NWF * 512, tuple(out.shape)
+    assert wfrag.is_contiguous() and bias.is_contiguous() and bias.dtype == torch.float32
+    ok = lib.nvw_produce_conditioning_f16(x_channels_last.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), out.data_ptr(), tiles, N, L, KF, NWF,
+                                          torch.cuda.current_stream().cuda_stream)
+    assert ok, "nvw_produce_conditioning_f16 refused its arguments"
+    return out
+
+
+def _upsample_trimmed_gemm(features, weight, bias, stride, pad_to=1):
+    """ConvTranspose1d(kernel = m * stride, stride) followed by the trimming of its (kernel - stride) tail, as m matrix products
+    (one per stride-long segment of the kernel, over the frames whose contribution survives the trimming):
+    out[b][f*stride + r][co] = bias[co] + sum_j sum_ci features[b][ci][f - j] * weight[ci][co][j*stride + r], channels last, the
+    channel dimension zero-padded to a multiple of `pad_to` (the fused producer reads whole 32-feature fragments).
     The library convolution compiles its kernels at first use on a machine without a kernel cache (MIOpen: a quarter of an hour
     of host time for bench.py's shapes on a fresh GPU box); a matrix product does not."""
     B, Ci, Fr = features.shape
     Co, K = weight.size(1), weight.size(2)
     m = K // stride
-    y = torch.matmul(features.transpose(1, 2), weight.reshape(Ci, Co * K)).view(B, Fr, Co, m, stride)     # [B][f][co][j][r]
-    out = y[:, :, :, 0, :].clone()
-    for j in range(1, min(m, Fr)):
-        out[:, j:] += y[:, :Fr - j, :, j, :]
-    # channels last, [B][samples][co]: the 1x1 convolution behind it is then ONE matrix product over all (utterance, sample) rows
-    return out.permute(0, 1, 3, 2).reshape(B, Fr * stride, Co) + bias[None, None, :]
+    Kp = (Ci + 31) // 32 * 32 if features.is_cuda else Ci           # (whole k-blocks for the GPU's matrix-product kernels)
+    ft = features.transpose(1, 2)                                    # [B][f][ci]
+    w = weight
+    if Kp != Ci:
+        ft = torch.nn.functional.pad(ft, (0, Kp - Ci))
+        w = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, Kp - Ci))
+    ft = ft.contiguous()
+    acc = None                                                       # [B][f][co][r]
+    for j in range(min(m, Fr)):
+        y = torch.matmul(ft[:, :Fr - j], w[:, :, j * stride:(j + 1) * stride].reshape(Kp, Co * stride)).view(B, Fr - j, Co, stride)
+        if acc is None:
+            acc = y
+        else:
+            acc[:, j:] += y
+    Cp = (Co + pad_to - 1) // pad_to * pad_to
+    out = torch.zeros(B, Fr * stride, Cp, dtype=acc.dtype, device=acc.device) if Cp != Co else torch.empty(B, Fr * stride, Co, dtype=acc.dtype, device=acc.device)
+    out.view(B, Fr, stride, Cp)[..., :Co] = acc.permute(0, 1, 3, 2)
+    out[..., :Co] += bias
+    return out
 
 
 def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, cond_weight, cond_bias, n_layers,
-                   layout="CBLN", dtype=None, precision=16, tiles=None, out=None, via_gemm=None):
+                   layout="CBLN", dtype=None, precision=16, tiles=None, out=None, via_gemm=None, fused=None):
     """WaveNet.get_cond_input (pytorch/wavenet.py:190-202) as a function of the module's tensors,
     run wherever `features` lives (the GPU): ConvTranspose1d upsampling, trimming of the
     (kernel - stride) transposed-convolution tail, the 1x1 `cond_layers` convolution.
@@ -192,10 +250,23 @@ def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, co
     `tiles` (NVWaveNetEngine.cond_tiles): the channel permutation and the gate's pre-scale are folded into the weights of the
     1x1 convolution -- its output channels simply come out in fragment order, scaled -- so the only extra work against "NLBC"
     is none: one permuting copy either way, and the generation kernels then run their packed path on the result as it is.
+    fused: None = with layout="packed", out= and fp16 features on the GPU the conditioning convolution runs in the engine's own
+    producer kernel (nvw_produce_conditioning_f16: fragment order written directly, no intermediate tensor); False forces the
+    torch operations below.
     via_gemm: None = on the GPU the two convolutions run as matrix products (_upsample_trimmed_gemm; same sums in another order),
     on the CPU as the torch convolutions the reference's modules call (bit-identical to them); True / False force either."""
     import torch.nn.functional as F
     gemm = features.is_cuda if via_gemm is None else via_gemm
+    can_fuse = (layout == "packed" and out is not None and precision == 16 and features.is_cuda and features.dtype == torch.float16
+                and upsample_weight.size(2) % upsample_stride == 0 and cond_weight.size(1) <= 128)
+    if (can_fuse if fused is None else fused):
+        # the engine's own producer: upsampling as one matrix product (small), then the conditioning convolution by an MFMA kernel
+        # that writes fragment order directly (csrc/cond_producer.hip)
+        assert can_fuse, "fused=True needs layout='packed', out=, fp16 features on the GPU and a kernel that is a multiple of the stride"
+        wfrag, bpos, KF, _ = cond_producer_weights(cond_weight, cond_bias, n_layers, precision)
+        xcl = _upsample_trimmed_gemm(features, upsample_weight, upsample_bias, upsample_stride, pad_to=32)   # [B][N][32 KF]
+        assert xcl.size(0) == tiles * 16, "writing into a packed buffer needs whole tiles (pad the batch)"
+        return produce_cond_packed(xcl, wfrag, bpos, out, tiles)
     if gemm and upsample_weight.size(2) % upsample_stride == 0:
         x = _upsample_trimmed_gemm(features, upsample_weight, upsample_bias, upsample_stride)         # [B][N][n_cond]
         # [B][N][n_cond] x [n_cond][channels] -> the [B][channels][N] the code below expects, as a view of the channels-last product

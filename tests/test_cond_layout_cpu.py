@@ -68,3 +68,36 @@ def test_get_cond_input_emits_the_fragment_order_of_its_own_output():
         assert a.shape == b.shape and a.dtype == b.dtype
         tol = (2.0 ** -9 if precision == 16 else 1e-5) * float(b.float().abs().max())
         assert float((a.float() - b.float()).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("n_cond,R,L,B,frames,win,stride", [(80, 64, 3, 32, 1, 1024, 16), (40, 64, 2, 16, 3, 16, 4), (100, 32, 2, 16, 2, 8, 4)])
+def test_fused_producer_operands_reproduce_the_packed_layout(n_cond, R, L, B, frames, win, stride):
+    """csrc/cond_producer.hip computes the conditioning convolution with MFMAs and stores each lane's result quads as the packed
+    layout's 16 bytes.  Its operand arrangement (nv_wavenet.py: cond_producer_weights) and its addressing, transcribed here with
+    the MFMA's lane roles (A: lane (g, i) = row i, k-slice g; B: lane (g, j) = column j, k-slice g; D: lane (g, j) = rows
+    4g..4g+3 of column j), must give what get_cond_input(layout="packed") gives (fp16 rounding apart); the GPU suite runs the
+    kernel itself against the same reference."""
+    from nv_wavenet_amd.nv_wavenet import _upsample_trimmed_gemm, cond_producer_weights
+    g = torch.Generator().manual_seed(7)
+    rnd = lambda *s, sc=1.0: (torch.rand(*s, generator=g) - 0.5) * sc
+    up_w, up_b = rnd(n_cond, n_cond, win, sc=0.2), rnd(n_cond, sc=0.2)
+    cw, cb = rnd(2 * R * L, n_cond, 1, sc=0.8), rnd(2 * R * L)
+    f = rnd(B, n_cond, frames, sc=2.0)
+    tiles, N = B // 16, frames * stride
+    NWF = 2 * R // 32
+    ref = torch.zeros(N, L, tiles, NWF, 4, 16, 8, dtype=torch.float16)
+    get_cond_input(f, up_w, up_b, stride, cw, cb, L, layout="packed", precision=16, tiles=tiles, out=ref, via_gemm=False, fused=False)
+    wfrag, bpos, KF, nwf = cond_producer_weights(cw, cb, L, 16)
+    assert nwf == NWF and KF == (n_cond + 31) // 32 and wfrag.shape == (L, NWF, 2, KF, 64, 8) and wfrag.dtype == torch.float16
+    x = torch.nn.functional.pad(_upsample_trimmed_gemm(f, up_w, up_b, stride), (0, 32 * KF - n_cond)).half().float()      # [B][N][32 KF]
+    A = wfrag.float().reshape(L, NWF, 2, KF, 4, 16, 8)                              # [l][wf][tt][kf][g][i][e]
+    xb = x.reshape(tiles, 16, N, KF, 4, 8)                                          # [tile][j][n][kf][g][e]
+    D = torch.einsum("lwtkgie,cjnkge->nlcwtij", A, xb)                              # rows i, columns j of result tile tt
+    out = torch.zeros(N, L, tiles, NWF, 4, 16, 8)
+    for gq in range(4):
+        for tt in range(2):
+            for r in range(4):
+                bias = bpos.reshape(L, NWF, 4, 8)[:, :, gq, tt * 4 + r]             # position (wf*4 + g)*8 + tt*4 + r
+                out[:, :, :, :, gq, :, tt * 4 + r] = D[:, :, :, :, tt, 4 * gq + r, :] + bias[None, :, None, :, None]
+    tol = 2.0 ** -9 * float(ref.float().abs().max())
+    assert float((out - ref.float()).abs().max()) <= tol

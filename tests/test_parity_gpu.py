@@ -809,6 +809,49 @@ def test_persistent_python_wrapper_seeded_audio():
     model.close()
 
 
+@pytest.mark.parametrize("n_cond,L,B,frames,win,stride", [(80, 20, 48, 2, 1024, 256), (40, 3, 16, 5, 32, 8), (100, 2, 32, 5, 8, 4)])
+def test_fused_conditioning_producer_against_the_torch_operations(n_cond, L, B, frames, win, stride):
+    """csrc/cond_producer.hip (nvw_produce_conditioning_f16): the model's conditioning convolution computed by MFMAs straight into
+    the engine's fragment order.  Held to get_cond_input's torch operations on the same inputs (which the engine consumes bit for
+    bit like its own packed copy, test_conditioning_produced_in_fragment_order) to fp16 rounding (the torch path rounds the scaled
+    weights, the bias and the sum separately: three units in the last place) and to a float64 evaluation of the convolution; samples that
+    are no multiple of the kernel's block of 8, features that are no multiple of 32, buffer contents beyond the produced samples."""
+    import torch
+    from nv_wavenet_amd.nv_wavenet import get_cond_input
+    R = 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s, sc=1.0: (torch.rand(*s, device="cuda", generator=g) - 0.5) * sc
+    h = torch.float16
+    up_w, up_b = rnd(n_cond, n_cond, win, sc=0.1).to(h), rnd(n_cond, sc=0.2).to(h)
+    cw, cb = rnd(2 * R * L, n_cond, 1, sc=0.6).to(h), rnd(2 * R * L).to(h)
+    f = rnd(B, n_cond, frames, sc=2.0).to(h)
+    tiles, N = B // 16, frames * stride
+    a = torch.full((N + 1, L, tiles, 2 * R // 32, 4, 16, 8), 7.0, dtype=h, device="cuda")
+    b = torch.zeros_like(a)
+    ra = get_cond_input(f, up_w, up_b, stride, cw, cb, L, layout="packed", precision=16, tiles=tiles, out=a[:N])            # fused (default)
+    get_cond_input(f, up_w, up_b, stride, cw, cb, L, layout="packed", precision=16, tiles=tiles, out=b[:N], fused=False)
+    torch.cuda.synchronize()
+    assert ra.data_ptr() == a.data_ptr()
+    assert bool((a[N] == 7.0).all()), "the producer wrote beyond the samples it was given"
+    af, bf = a[:N].float(), b[:N].float()
+    assert float(af.abs().max()) > 1.0 and len(torch.unique(a[:N])) > 1000
+    # (the torch path rounds the scaled weights, the scaled bias and the matrix product to fp16 separately, so its error is relative
+    #  to the terms, not to their sum: a loose bar here, the tight one against float64 below)
+    err = (af - bf).abs()
+    k = int(err.argmax())
+    assert bool((err <= 3.0 * 2.0 ** -10 * (bf.abs() + 4.0)).all()), (float(err.max()), float(af.flatten()[k]), float(bf.flatten()[k]), k)
+    # float64 on the CPU, from the very fp16 operands
+    c64 = get_cond_input(f.double().cpu(), up_w.double().cpu(), up_b.double().cpu(), stride, cw.double().cpu(), cb.double().cpu(), L,
+                         layout="NLBC", via_gemm=True)                                    # [N][L][B][2R], reference channel order
+    from nv_wavenet_amd.nv_wavenet import pack_cond_input
+    want = pack_cond_input(c64.float(), 16, tiles)[:N].float()                            # packed, pre-scaled, rounded once
+    errw = (af.cpu() - want).abs()
+    kw = int(errw.argmax())
+    print("fused producer: max |fused - torch| %.2e, max |fused - float64| %.2e at %d (%.4f vs %.4f), max |torch - float64| %.2e" %
+          (float(err.max()), float(errw.max()), kw, float(af.flatten()[kw]), float(want.flatten()[kw]), float((bf.cpu() - want).abs().max())))
+    assert bool((errw <= 2.0 ** -9 * want.abs() + 4e-3).all()), float(errw.max())        # (the upsampled features are rounded to fp16 in between)
+
+
 def test_python_wrapper_fp16_conditioning_in_place_and_get_cond_input():
     """SURVEY.md 8f rank 1 with T_data conditioning: get_cond_input(..., layout="NLBC", dtype=torch.float16) emits the upsampled
     conditioning in the fp16 engine's own element type and layout, NVWaveNetEngine(precision=16).infer reads that tensor in
