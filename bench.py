@@ -646,13 +646,14 @@ def main():
         e2e["max_realtime_batch_per_gpu"] = best
         # ... and with the producer of that conditioning in the loop (the model's own upsampling + conditioning convolution, run on
         # the GPU between the generation launches, landing in fragment order): what a deployment gets end to end
-        wp = {"definition": "per chunk of 256 samples: get_cond_input(layout='packed') (ConvTranspose1d upsampling of [B][80][frames] "
-                            "fp16 features + the 1x1 conditioning convolution with the engine's channel order and gate pre-scale folded "
-                            "into its weights, torch on the GPU) writes the engine's fragment order in place, then the generation launch "
+        wp = {"definition": "per chunk of 256 samples: get_cond_input(layout='packed') (upsampling of [B][80][frames] fp16 features as matrix "
+                            "products, then the 1x1 conditioning convolution -- the engine's channel order and gate pre-scale folded into its "
+                            "weights -- by the engine's own MFMA producer kernel, nvw_produce_conditioning_f16) writes the engine's fragment "
+                            "order in place, then the generation launch "
                             "of that chunk; same stream (every CU holds a generation workgroup for a whole launch); 4 chunks, the first "
                             "production inside the timed region", "sweep_khz": {}}
         best_wp = None
-        for cand in sorted(set([B, B * 3 // 4, B // 2, B * 3 // 8, B // 4]), reverse=True):
+        for cand in sorted(set([B, B * 3 // 4, B // 2, B * 3 // 8, B // 4] + [c for c in (32 * ncu, 28 * ncu) if c < B]), reverse=True):
             cand = max(16, cand // 64 * 64)
             if extras_left() < 20:
                 skipped.append("end_to_end.with_producer.%d" % cand)
