@@ -38,6 +38,11 @@ typedef struct nvw_engine nvw_engine;
 /* consumer callback of nvw_run_chunks: (yOut, first sample of the chunk, samples in it, user) */
 typedef void (*nvw_consume_fn)(int* yOut, int init_sample, int count, void* user);
 
+/* Revision of this interface.  It changes whenever an entry point or the meaning of an argument does -- in particular the
+ * organisation codes of nvw_create_ex, which were renumbered once (round 3) and lost code 9 in round 4: a caller built against
+ * another revision should check this instead of finding a different kernel behind a number.  4 = this header. */
+#define NVW_ABI_VERSION 4
+int nvw_abi_version(void);
 int nvw_supported(int R, int S, int A, int precision);
 /* writes up to `max` (R,S,A,precision) quadruples into out[4*i..], returns how many exist */
 int nvw_list_supported(int* out, int max);

@@ -23,6 +23,7 @@ CONSUME_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
 
 # every symbol of include/nv_wavenet_c.h and include/wavenet_infer.h
 SIGNATURES = {
+    "nvw_abi_version": (C.c_int, []),
     "nvw_supported": (C.c_int, [C.c_int] * 4),
     "nvw_list_supported": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "nvw_create": (C.c_void_p, [C.c_int] * 10),
@@ -78,6 +79,12 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+ABI_VERSION = 4            # NVW_ABI_VERSION of include/nv_wavenet_c.h this package was written against
+if lib.nvw_abi_version() != ABI_VERSION:
+    raise ImportError("nv_wavenet_amd: %s implements revision %d of include/nv_wavenet_c.h, this package expects %d: rebuild it "
+                      "(make -C nv_wavenet_amd/csrc)" % (LIB_PATH, lib.nvw_abi_version(), ABI_VERSION))
 
 
 def addr(x):

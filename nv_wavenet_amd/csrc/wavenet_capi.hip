@@ -29,6 +29,7 @@ const Entry* findEntry(int R, int S, int A, int P) {
 
 extern "C" {
 
+int nvw_abi_version(void) { return NVW_ABI_VERSION; }
 int nvw_supported(int R, int S, int A, int precision) { return findEntry(R, S, A, precision) != NULL; }
 
 int nvw_list_supported(int* out, int max) {
