@@ -77,11 +77,11 @@ if "parity" in what:
     except AssertionError as ex:
         log("fp16 bars FAILED:", ex)
 
-    # 3. ragged multi-workgroup batch, one and two tiles per wave
+    # 3. ragged multi-workgroup batch
     case = cases.Case("C3_o1_b200", 31, [], cases.Shape(64, 256, 256, 20, 200, 40, 32), 3, 1, 40)
     t = util.gen_o1(case, half=True)
     gw, _ = run(case, t, 16, "wg", False)
-    for mode in ("bcast", "bcast2"):
+    for mode in ("bcast",):
         gb, info = run(case, t, 16, mode, False)
         same = np.array_equal(gb["y"], gw["y"])
         log("B=200", info, "== wg:", same)
@@ -110,8 +110,8 @@ if "time" in what:
     import bench
     w = bench.make_weights()
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    pts = [("wg3", 4, 48 * ncu), ("bcast1", 8, 64 * ncu), ("bcast2", 9, 128 * ncu), ("bcast1", 8, 64), ("bcast2", 9, 128)]
-    if os.environ.get("R4_POINTS"):       # e.g. "bcast1:8:64,bcast2:9:128"
+    pts = [("wg3", 4, 48 * ncu), ("bcast1", 8, 64 * ncu), ("auto", 0, 96 * ncu), ("bcast1", 8, 64)]
+    if os.environ.get("R4_POINTS"):       # e.g. "bcast1:8:64,wg3:4:12288" (name : organisation code : utterances)
         pts = [(a, int(b), int(c)) for a, b, c in (x.split(":") for x in os.environ["R4_POINTS"].split(","))]
     for name, org, B in pts:
         t0 = time.time()
