@@ -105,6 +105,17 @@ def make_weights(sh=HEAD, seed=3):
     return w
 
 
+N_COND = 80                                   # feature channels of the reference's model (pytorch/config.json: n_cond_channels)
+
+
+def make_cond_layers(sh=HEAD, seed=4):
+    """The model's conditioning convolution (cond_layers: [2R*L][n_cond] + bias) at magnitudes that give the conditioning the
+    standard deviation COND_STD for features of unit variance."""
+    rng = np.random.default_rng(seed)
+    u = lambda std, *s: ((rng.random(s, dtype=np.float32) - 0.5) * (std * np.sqrt(12.0))).astype(np.float32)
+    return u(COND_STD / np.sqrt(N_COND), 2 * sh.R * sh.L, N_COND), u(0.1, 2 * sh.R * sh.L)
+
+
 def build_engine(w, B, N, sh=HEAD, precision=16, impl=0, organisation=0):
     from nv_wavenet_amd import WavenetEngine
     e = WavenetEngine(sh.R, sh.S, sh.A, sh.L, sh.maxD, B, N, impl=impl, tanhEmbed=True, precision=precision,
@@ -178,6 +189,18 @@ def steady_engine(w, B, n_timed, seed=11, in_place=None, organisation=0):
         e.resetHistory()
         for first in range(0, N, COND_BLOCK):
             e.packConditioning(block[:min(COND_BLOCK, N - first)], first, min(COND_BLOCK, N - first))
+    elif in_place == "features":
+        # the conditioning computed in the generation kernel (round 5): the engine gets cond_layers once and, per sample and
+        # utterance, N_COND upsampled feature values (unit variance, one reused COND_BLOCK-sample block)
+        Wc, bc = make_cond_layers()
+        e.setConditioningWeights(Wc, bc)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed + 1)
+        xb = torch.randn(B, N_COND, COND_BLOCK, dtype=torch.float32, device="cuda", generator=g).half()
+        e.resetHistory()
+        for first in range(0, N, COND_BLOCK):
+            e.packFeatures(xb[:, :, :min(COND_BLOCK, N - first)], first)
+        del xb
     elif in_place == "fragments":
         # the caller's own buffer in the engine's fragment order (what a model's conditioning convolution emits with the
         # channel permutation and the gate pre-scale folded into its weights: nv_wavenet.py get_cond_input(layout="packed"))

@@ -40,8 +40,9 @@ typedef void (*nvw_consume_fn)(int* yOut, int init_sample, int count, void* user
 
 /* Revision of this interface.  It changes whenever an entry point or the meaning of an argument does -- in particular the
  * organisation codes of nvw_create_ex, which were renumbered once (round 3) and lost code 9 in round 4: a caller built against
- * another revision should check this instead of finding a different kernel behind a number.  4 = this header. */
-#define NVW_ABI_VERSION 4
+ * another revision should check this instead of finding a different kernel behind a number.  5 = this header (round 5: the
+ * feature-conditioning entry points below). */
+#define NVW_ABI_VERSION 5
 int nvw_abi_version(void);
 int nvw_supported(int R, int S, int A, int precision);
 /* writes up to `max` (R,S,A,precision) quadruples into out[4*i..], returns how many exist */
@@ -119,6 +120,36 @@ int nvw_cond_tiles(nvw_engine* e);
  * Asynchronous on `stream`; returns 0 when the arguments are out of range (1 <= kfrags <= 4) or the launch failed. */
 int nvw_produce_conditioning_f16(const void* x, const void* wfrag, const float* bias, void* out, int tiles, int num_samples,
                                  int num_layers, int kfrags, int nwf, void* stream);
+/* CONDITIONING COMPUTED IN THE GENERATION KERNEL (round 5).  The reference's pipeline builds cond_input = cond_layers(upsample(
+ * features)) -- [2R][B][L][N], 2R*L values per utterance and sample -- in PyTorch and hands it to the engine
+ * (pytorch/wavenet.py:190-202, inference.py:52-53).  Here the 1x1 convolution `cond_layers` moves INTO the generation kernel: the
+ * caller hands over its weights once and, per utterance, only the upsampled features (n_cond values per utterance and sample);
+ * Lh[t][l] = Wcond[l] c[t] + bcond[l] is computed where it is consumed (n_cond more k steps of the gate GEMM), and the
+ * [N][L][B][2R] tensor is never built.  An additional contract beside nvw_set_inputs / nvw_set_conditioning*, which stay as they are.
+ *   nvw_max_cond_channels          feature channels the kernels are built for (80 = the reference's config.json)
+ *   nvw_set_conditioning_weights   Wcond [L][2R][n_cond] (cond_layers.weight, [2R*L][n_cond][1] as it is), bcond [L][2R]; fp32, host
+ *                                  or device, copied.  0 when n_cond is out of range (nothing changes).
+ *   nvw_set_features               the upsampled features of the whole utterance from a device tensor of `precision`-bit floats
+ *                                  (32 | 16) addressed x[b*b_stride + c*c_stride + t*t_stride] (upsample output [B][n_cond][T]:
+ *                                  strides n_cond*T, T, 1); copied into the engine's fragment order; resets the history like
+ *                                  nvw_set_inputs; pair with nvw_set_selector_seed or nvw_set_selectors.
+ *   nvw_pack_features              samples [first_sample, first_sample + count) only (x points at sample first_sample),
+ *                                  asynchronously on `stream`, history untouched: streaming chunk by chunk like nvw_pack_conditioning
+ *   nvw_set_conditioning_features  features the caller produced in fragment order itself, used in place:
+ *                                  [num_samples][nvw_cond_tiles(e)][nvw_feature_fragments(e)][64][8 fp16 | 4 fp32] of the engine's
+ *                                  T_data; fragment kf, lane (g, j), element e = channel (kf*TPF + (e>>2))*16 + 4g + (e&3) of utterance
+ *                                  tile*16 + j (TPF = 2 fp16 | 1 fp32), zero beyond n_cond; `elems` = the buffer's size
+ * All return 1 on success, 0 (after a message) when refused.  Runs that follow launch wn::wavenet_wg<.., RAW=3> whatever the
+ * engine's organisation. */
+int nvw_max_cond_channels(void);
+int nvw_set_conditioning_weights(nvw_engine* e, const float* Wcond, const float* bcond, int n_cond);
+int nvw_feature_fragments(nvw_engine* e);
+size_t nvw_feature_elems(nvw_engine* e, int num_samples);
+int nvw_set_conditioning_features(nvw_engine* e, const void* frags, int num_samples, size_t elems);
+int nvw_pack_features(nvw_engine* e, const void* x, int precision, long long b_stride, long long c_stride, long long t_stride,
+                      int first_sample, int count, void* stream);
+int nvw_set_features(nvw_engine* e, const void* x, int precision, long long b_stride, long long c_stride, long long t_stride,
+                     int num_samples);
 /* the selector half of nvw_set_inputs ([num_samples][batch] uniform draws, host or device); conditioning and history untouched */
 void nvw_set_selectors(nvw_engine* e, float* output_selectors, int num_samples);
 /* Multi-CU (wavenet_chain) launches need all their workgroups resident at once; when other work holds CUs a launch gives up

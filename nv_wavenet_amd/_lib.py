@@ -43,6 +43,13 @@ SIGNATURES = {
     "nvw_set_conditioning_packed_n": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_size_t]),
     "nvw_cond_tiles": (C.c_int, [C.c_void_p]),
     "nvw_produce_conditioning_f16": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "nvw_max_cond_channels": (C.c_int, []),
+    "nvw_set_conditioning_weights": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int]),
+    "nvw_feature_fragments": (C.c_int, [C.c_void_p]),
+    "nvw_feature_elems": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "nvw_set_conditioning_features": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_size_t]),
+    "nvw_pack_features": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
+    "nvw_set_features": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]),
     "nvw_set_selectors": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_chain_status": (C.c_uint, [C.c_void_p]),
     "nvw_chain_fallbacks": (C.c_uint, [C.c_void_p]),
@@ -75,16 +82,21 @@ SIGNATURES = {
     "get_A": (C.c_int, []),
 }
 
+ABI_VERSION = 5            # NVW_ABI_VERSION of include/nv_wavenet_c.h this package was written against
+# (checked before the other symbols are bound, so that an older library fails with the rebuild hint, not an AttributeError)
+_abi = getattr(lib, "nvw_abi_version", None)
+_have = None
+if _abi is not None:
+    _abi.restype, _abi.argtypes = C.c_int, []
+    _have = _abi()
+if _have != ABI_VERSION:
+    raise ImportError("nv_wavenet_amd: %s implements revision %s of include/nv_wavenet_c.h, this package expects %d: rebuild it "
+                      "(make -C nv_wavenet_amd/csrc)" % (LIB_PATH, "<none: too old>" if _have is None else _have, ABI_VERSION))
+
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
     _fn.restype = _res
     _fn.argtypes = _args
-
-
-ABI_VERSION = 4            # NVW_ABI_VERSION of include/nv_wavenet_c.h this package was written against
-if lib.nvw_abi_version() != ABI_VERSION:
-    raise ImportError("nv_wavenet_amd: %s implements revision %d of include/nv_wavenet_c.h, this package expects %d: rebuild it "
-                      "(make -C nv_wavenet_amd/csrc)" % (LIB_PATH, lib.nvw_abi_version(), ABI_VERSION))
 
 
 def addr(x):

@@ -16,6 +16,13 @@ struct nvw_engine {
     virtual void setConditioningDirect(const void*, int, int) = 0;
     virtual void setConditioningPacked(const void*, int) = 0;
     virtual int condTiles() = 0;
+    virtual bool setConditioningWeights(const float*, const float*, int) = 0;
+    virtual int featureFragments() = 0;
+    virtual size_t featureElems(int) = 0;
+    virtual void setConditioningFeatures(const void*, int) = 0;
+    virtual void packFeatures(const void*, int, long long, long long, long long, int, int, hipStream_t) = 0;
+    virtual void setFeatures(const void*, int, long long, long long, long long, int) = 0;
+    virtual int conditioningChannels() = 0;
     virtual size_t condPackedElems(int) = 0;
     virtual void setSelectors(float*, int) = 0;
     virtual bool run_range(int, int, int, int, hipStream_t) = 0;
@@ -59,6 +66,15 @@ struct EngineImpl : nvw_engine {
     void setConditioningDirect(const void* Lh, int n, int prec) override { eng.setConditioningDirect(Lh, n, prec); }
     void setConditioningPacked(const void* frags, int n) override { eng.setConditioningPacked(frags, n); }
     int condTiles() override { return eng.condTiles(); }
+    bool setConditioningWeights(const float* W, const float* b, int n) override { return eng.setConditioningWeights(W, b, n); }
+    int featureFragments() override { return eng.featureFragments(); }
+    size_t featureElems(int n) override { return eng.featureElems(n); }
+    void setConditioningFeatures(const void* f, int n) override { eng.setConditioningFeatures(f, n); }
+    void packFeatures(const void* x, int prec, long long bS, long long cS, long long tS, int first, int count, hipStream_t s) override {
+        eng.packFeatures(x, prec, bS, cS, tS, first, count, s);
+    }
+    void setFeatures(const void* x, int prec, long long bS, long long cS, long long tS, int n) override { eng.setFeatures(x, prec, bS, cS, tS, n); }
+    int conditioningChannels() override { return eng.conditioningChannels(); }
     size_t condPackedElems(int n) override { return eng.condPackedElems(n); }
     void setSelectors(float* sel, int n) override { eng.setSelectors(sel, n); }
     bool run_range(int i, int c, int n, int b, hipStream_t s) override { return eng.run_range(i, c, n, b, s); }

@@ -80,6 +80,10 @@ protected:
     using C = wn::Cfg<F16, R, S, A, 1>;   // stream / layout constants do not depend on BT
     using CC = wn::CCfg<F16, R, S, A>;     // multi-CU chain
     using elem = typename wn::Prec<F16>::elem;
+    // in-kernel conditioning (setConditioningWeights + features): the stream that also carries Wcond
+    static constexpr int KFC = wn::feat_kfc<F16>();                    // feature fragments per tile and sample
+    static constexpr int KC = KFC * 16 * wn::Prec<F16>::TPF;           // channels the features are padded to
+    using CF = wn::Cfg<F16, R, S, A, 1, KFC>;
 
     Implementation m_implementation;
     int m_numLayers, m_maxBatch, m_maxSamples, m_maxDilation, m_tiles, m_numCUs;
@@ -101,6 +105,18 @@ protected:
     int m_condRawKind;        // 1: fp32, 2: fp16 (T_data of the fp16 engine)
     const void* m_condUser;   // or: the caller's device buffer ALREADY in the engine's fragment order (setConditioningPacked)
     int m_condUserSamples;    // samples that buffer holds (+ one padding sample)
+    // in-kernel conditioning (round 5): Lh = Wcond c + bcond computed by wavenet_wg from the upsampled features
+    elem* m_wblobF;           // the weight streams with the conditioning weights in every layer's part (Cfg<.., KFC>)
+    float* m_biasF;           // bias table with bcond added to the gate biases
+    float* m_condW;           // [L][KC][2R] fp32: the conditioning weight, col-major per layer, channels zero-padded
+    float* m_condB;           // [L][2R]
+    int2* m_restream;         // fragment map plain stream -> that stream (restream_kernel)
+    int m_restreamN;
+    int m_nCond;              // channels of the model's features (0: no conditioning weights handed over)
+    bool m_featDirty;         // m_wblobF / m_biasF are behind m_wblob / m_bias / m_condW
+    elem* m_feat;             // features packed by the engine (packFeatures), [maxSamples][m_tiles][KFC] fragments
+    const void* m_featPtr;    // the features the runs read: m_feat or the caller's buffer in that order (setConditioningFeatures)
+    int m_featSamples;
     float* m_outputSelectors;
     elem* m_ring;
     int *m_yInPrev, *m_yInCur, *m_yOut;
@@ -196,6 +212,7 @@ protected:
         return nEmb ? launchK<BT, true, DUMP, RAW>(p, tiles, nEmb, stream) : launchK<BT, false, DUMP, RAW>(p, tiles, 0, stream);
     }
     template <int BT, bool DUMP> bool launchD(wn::Params& p, int tiles, hipStream_t stream) {
+        if (p.condRawKind == 3) return launchE<BT, DUMP, 3>(p, tiles, stream);
         if constexpr (F16) {
             if (p.condRawKind == 2) return launchE<BT, DUMP, 2>(p, tiles, stream);
         }
@@ -218,6 +235,8 @@ protected:
         allowLdsK<BT, true, DUMP, 0>();
         allowLdsK<BT, false, DUMP, 1>();
         allowLdsK<BT, true, DUMP, 1>();
+        allowLdsK<BT, false, DUMP, 3>();
+        allowLdsK<BT, true, DUMP, 3>();
         if constexpr (F16) {
             allowLdsK<BT, false, DUMP, 2>();
             allowLdsK<BT, true, DUMP, 2>();
@@ -323,6 +342,8 @@ public:
         : m_implementation((Implementation)impl), m_numLayers(numLayers), m_maxBatch(batchSize),
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
           m_num_samples_per_chunk(0), m_lastStride(numSamples), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0), m_condUser(NULL), m_condUserSamples(0),
+          m_wblobF(NULL), m_biasF(NULL), m_condW(NULL), m_condB(NULL), m_restream(NULL), m_restreamN(0), m_nCond(0), m_featDirty(true),
+          m_feat(NULL), m_featPtr(NULL), m_featSamples(0),
           m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0), m_ringShadow(NULL), m_histShadow(NULL),
           m_chainTimeoutTicks(wn::kChainTimeoutTicks), m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL),
           m_mulaw(NULL), m_pcmUser(NULL), m_pcmUserElems(0), m_clk(NULL), m_clkOn(false), m_stageUsed(0) {
@@ -439,6 +460,12 @@ public:
         gpuErrChk(hipFree(m_embedPrev));
         gpuErrChk(hipFree(m_embedCur));
         if (m_cond) gpuErrChk(hipFree(m_cond));
+        if (m_wblobF) gpuErrChk(hipFree(m_wblobF));
+        if (m_biasF) gpuErrChk(hipFree(m_biasF));
+        if (m_condW) gpuErrChk(hipFree(m_condW));
+        if (m_condB) gpuErrChk(hipFree(m_condB));
+        if (m_restream) gpuErrChk(hipFree(m_restream));
+        if (m_feat) gpuErrChk(hipFree(m_feat));
         gpuErrChk(hipFree(m_outputSelectors));
         gpuErrChk(hipFree(m_ring));
         gpuErrChk(hipFree(m_yInPrev));
@@ -503,6 +530,74 @@ public:
         convertTo(m_embedCur, embedCur, (size_t)A * R);
         gpuErrChk(hipStreamSynchronize(0));
     }
+    // ---- in-kernel conditioning (beyond the reference class; SURVEY.md 8f rank 1 "feeding Lh directly") -------------------------
+    // The model's conditioning convolution (cond_layers of pytorch/wavenet.py:73-74,197): Wcond [L][2R][nCond] (its weight
+    // [2R*L][nCond][1] as it is), bcond [L][2R], fp32, host or device, copied.  With them and the upsampled features
+    // (setConditioningFeatures / packFeatures) wavenet_wg computes Lh[t][l] = Wcond[l] c[t] + bcond[l] itself: the [N][L][B][2R]
+    // tensor of setInputs is never built.  false: more channels than the kernels are built for (kCondChannelsMax).
+    bool setConditioningWeights(const float* Wcond, const float* bcond, int nCond) {
+        if (nCond <= 0 || nCond > wn::kCondChannelsMax) return false;
+        const size_t nW = (size_t)m_numLayers * 2 * R * nCond, nB = (size_t)m_numLayers * 2 * R;
+        stageBegin(nW + nB + 8);
+        if (!m_condW) {
+            gpuErrChk(hipMalloc(&m_condW, (size_t)m_numLayers * KC * 2 * R * sizeof(float)));
+            gpuErrChk(hipMalloc(&m_condB, nB * sizeof(float)));
+        }
+        gpuErrChk(hipMemsetAsync(m_condW, 0, (size_t)m_numLayers * KC * 2 * R * sizeof(float), 0));
+        const float* dW = onDevice(Wcond, nW);
+        hipLaunchKernelGGL(wn::cond_weight_arrange_kernel, dim3(gridFor(nW)), dim3(256), 0, 0, m_condW, dW, m_numLayers, 2 * R, nCond, KC);
+        gpuErrChk(hipGetLastError());
+        gpuErrChk(hipMemcpyAsync(m_condB, bcond, nB * sizeof(float), hipMemcpyDefault, 0));
+        gpuErrChk(hipStreamSynchronize(0));
+        m_nCond = nCond;
+        m_featDirty = true;
+        return true;
+    }
+    int conditioningChannels() const { return m_nCond; }
+    int featureFragments() const { return KFC; }
+    // elements (T_data) of numSamples samples of features in fragment order: numSamples x condTiles() x KFC x 64 x EPL
+    size_t featureElems(int numSamples) const { return (size_t)numSamples * m_tiles * KFC * C::FRAG_ELEMS; }
+    // Features the caller has produced in fragment order (device memory, T_data; pack_features_kernel documents the order):
+    // used in place, kept alive and unchanged until the runs that follow have completed.  Resets the history like setInputs.
+    void setConditioningFeatures(const void* frags, int numSamples) {
+        assert(numSamples > 0 && numSamples <= m_maxSamples && m_nCond > 0);
+        assert(isDevicePtr(frags));
+        resetHistory(0);
+        gpuErrChk(hipStreamSynchronize(0));
+        dropLhConditioning();
+        m_featPtr = frags;
+        m_featSamples = numSamples;
+    }
+    // Samples [firstSample, firstSample + count) of the features from a device tensor of `precision`-bit floats addressed as
+    // x[b * bStride + c * cStride + (t - firstSample) * tStride] (the model's upsample output [B][nCond][T] has strides (nCond*T, T, 1);
+    // channels-last [B][T][nCond] works as well), into the engine's own buffer, asynchronously on `stream`.  History untouched.
+    void packFeatures(const void* x, int precision, long long bStride, long long cStride, long long tStride, int firstSample, int count,
+                      hipStream_t stream = 0) {
+        assert(firstSample >= 0 && count > 0 && firstSample + count <= m_maxSamples && m_nCond > 0);
+        assert(precision == 32 || precision == 16);
+        assert(isDevicePtr(x));
+        if (!m_feat) {
+            gpuErrChk(hipMalloc(&m_feat, featureElems(m_maxSamples) * sizeof(elem)));
+            gpuErrChk(hipMemsetAsync(m_feat, 0, featureElems(m_maxSamples) * sizeof(elem), stream));
+            gpuErrChk(hipStreamSynchronize(stream));
+        }
+        dropLhConditioning();
+        m_featPtr = m_feat;
+        m_featSamples = m_maxSamples;      // (run_partial of a chunk only reads what has been packed: the caller's ordering, as with packConditioning)
+        const int tilesUsed = (m_maxBatch + 15) / 16;
+        const size_t nblk = (size_t)tilesUsed * ((count + 7) / 8);
+        hipLaunchKernelGGL((wn::pack_features_kernel<F16>), dim3((unsigned)(nblk > 65536 ? 65536 : nblk)), dim3(256), 0, stream,
+                           m_feat + featureElems(firstSample), x, precision, bStride, cStride, tStride, m_nCond, m_maxBatch, count, m_tiles,
+                           tilesUsed);
+        gpuErrChk(hipGetLastError());
+    }
+    // the whole utterance at once (resets the history like setInputs; synchronises)
+    void setFeatures(const void* x, int precision, long long bStride, long long cStride, long long tStride, int numSamples) {
+        resetHistory(0);
+        packFeatures(x, precision, bStride, cStride, tStride, 0, numSamples, 0);
+        gpuErrChk(hipStreamSynchronize(0));
+    }
+    bool conditioningFromFeatures() const { return m_featPtr != NULL; }
     // col-major Wprev,Wcur 2RxR; Bh 2R; Wres RxR; Bres R; Wskip SxR; Bskip S (nv_wavenet.cuh:400-409)
     virtual void setLayerWeights(int layer, float* Wprev, float* Wcur, float* Bh, float* Wres, float* Bres,
                                  float* Wskip, float* Bskip) {
@@ -524,6 +619,7 @@ public:
                            (int)C::streamPos(layer, C::O_RES, m_numLayers), (int)C::streamPos(layer, C::O_SKIP, m_numLayers));
         gpuErrChk(hipGetLastError());
         gpuErrChk(hipStreamSynchronize(0));
+        m_featDirty = true;
     }
     // col-major Wzs AxS, Bzs A, Wza AxA, Bza A (nv_wavenet.cuh:410-415)
     virtual void setOutWeights(float* Wzs, float* Bzs, float* Wza, float* Bza) {
@@ -534,6 +630,7 @@ public:
         gpuErrChk(hipMemcpyAsync(headBias(), Bzs, A * sizeof(float), hipMemcpyDefault, 0));
         gpuErrChk(hipMemcpyAsync(headBias() + A, Bza, A * sizeof(float), hipMemcpyDefault, 0));
         gpuErrChk(hipStreamSynchronize(0));
+        m_featDirty = true;
     }
 
     // Lh: [maxSamples][L][maxBatch][2R] conditioning, outputSelectors: [maxSamples][maxBatch]
@@ -567,6 +664,7 @@ public:
         m_condRaw = NULL;
         m_condRawKind = 0;
         m_condUser = NULL;
+        m_featPtr = NULL;
         const size_t rows = (size_t)count * m_numLayers;
         const size_t srcPerRow = (size_t)m_maxBatch * 2 * R;
         const size_t dstPerRow = (size_t)m_tiles * 16 * 2 * R;
@@ -619,6 +717,7 @@ public:
         m_condRawKind = precision == 16 ? 2 : 1;
         m_condRawSamples = numSamples;
         m_condUser = NULL;
+        m_featPtr = NULL;
     }
     // Conditioning that the caller has PRODUCED in the engine's own fragment order (round 3): T_data
     // [numSamples + 1][L][condTiles()][wave][fragment][lane][EPL], gate rows pre-scaled -- exactly what packConditioning writes
@@ -634,6 +733,7 @@ public:
         gpuErrChk(hipStreamSynchronize(0));
         m_condRaw = NULL;
         m_condRawKind = 0;
+        m_featPtr = NULL;
         m_condUser = frags;
         m_condUserSamples = numSamples;      // (run_partial refuses to generate past what the caller handed over)
     }
@@ -691,13 +791,13 @@ public:
     void kernelInfo(int batch_size, bool dumpActivations, char* buf, int n) const {
         const int tiles = (batch_size + 15) / 16;
         const bool dump = F16 ? dumpActivations : true;
-        if (isChain()) {
+        if (isChain() && !m_featPtr) {
             snprintf(buf, n, "wn::wavenet_chain<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d wgs=%d lds=%zu",
                      F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, tiles, m_chainStages * tiles,
                      CC::ldsBytes());
             return;
         }
-        if (isBcast() && !m_condRaw) {
+        if (isBcast() && !m_condRaw && !m_featPtr) {
             const int btw = 1;
             const int emb = bcastEmb(dump);
             snprintf(buf, n, "wn::wavenet_bcast<%s,%d,%d,%d,BTW=%d,EMBLDS=%d,DUMP=%d> tiles/wave=%d wgs=%d lds=%zu", F16 ? "fp16" : "fp32", R, S,
@@ -715,7 +815,7 @@ public:
             }
         }
         snprintf(buf, n, "wn::wavenet_wg<%s,%d,%d,%d,BT=%d,EMBLDS=%d,DUMP=%d,RAW=%d> tiles/wg=%d wgs=%d lds=%zu",
-                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, m_condRaw ? m_condRawKind : 0, bt, (tiles + bt - 1) / bt, lds);
+                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, m_featPtr ? 3 : m_condRaw ? m_condRawKind : 0, bt, (tiles + bt - 1) / bt, lds);
     }
 
     // ---- debug getters: last generated sample's activations, reference layouts --------------
@@ -807,7 +907,8 @@ public:
         assert(batch_size % batch_size_per_block == 0);
         assert(batch_size > 0 && batch_size <= m_maxBatch);
         assert(num_samples <= m_maxSamples);
-        assert(m_condRaw != NULL || m_cond != NULL || m_condUser != NULL);  // some conditioning has been handed over
+        assert(m_condRaw != NULL || m_cond != NULL || m_condUser != NULL || m_featPtr != NULL);  // some conditioning has been handed over
+        assert(m_featPtr == NULL || num_samples <= m_featSamples);
         assert(m_condRaw == NULL || num_samples <= m_condRawSamples);      // ... and the in-place tensor covers the run
         assert(m_condUser == NULL || num_samples <= m_condUserSamples);    // ... and so does a caller's packed buffer
         assert(m_pcmUser == NULL || m_pcmUserElems == 0 || m_pcmUserElems >= (size_t)batch_size * num_samples);
@@ -822,6 +923,15 @@ public:
         p.cond = m_condUser ? m_condUser : m_cond;
         p.condRaw = m_condRaw;
         p.condRawKind = m_condRaw ? m_condRawKind : 0;
+        p.feat = NULL;
+        if (m_featPtr) {
+            // the conditioning is computed by wavenet_wg from the features: its own stream (with Wcond) and bias table (with bcond)
+            if (m_featDirty) buildFeatStream(stream);
+            p.wblob = m_wblobF;
+            p.bias = m_biasF;
+            p.feat = m_featPtr;
+            p.condRawKind = 3;
+        }
         p.gate = NULL;
         p.sel = m_outputSelectors;
         p.ring = m_ring;
@@ -838,7 +948,7 @@ public:
         p.batch = batch_size;
         p.maxBatch = m_maxBatch;
         p.numSamples = num_samples;
-        p.condSamples = m_condRaw ? m_condRawSamples : m_maxSamples;
+        p.condSamples = m_featPtr ? m_featSamples : m_condRaw ? m_condRawSamples : m_maxSamples;
         p.initSample = init_sample;
         p.count = m_num_samples_per_chunk ? m_num_samples_per_chunk : num_samples;
         if (p.initSample + p.count > num_samples) p.count = num_samples - p.initSample;
@@ -869,7 +979,9 @@ public:
         if (p.count <= 0) return true;
 
         const int tiles = (batch_size + 15) / 16;
-        bool result = isChain() ? launchChain(p, tiles, stream) : (isBcast() && !m_condRaw) ? launchBcast(p, tiles, stream) : launchWg(p, tiles, stream);
+        // (computing the conditioning from the features is wavenet_wg's: chain / bcast engines run it for such a launch)
+        bool result = m_featPtr ? launchWg(p, tiles, stream)
+                      : isChain() ? launchChain(p, tiles, stream) : (isBcast() && !m_condRaw) ? launchBcast(p, tiles, stream) : launchWg(p, tiles, stream);
         if (m_pcmUser != NULL) {
             // the indices of a finished sample are final: the expansion is a per-element map of yOut
             hipLaunchKernelGGL(wn::mulaw_pcm_kernel, dim3(gridFor((size_t)batch_size * p.count)), dim3(256), 0, stream,
@@ -907,6 +1019,44 @@ public:
     }
 
 protected:
+    void dropLhConditioning() {
+        m_condRaw = NULL;
+        m_condRawKind = 0;
+        m_condUser = NULL;
+    }
+    // m_wblobF / m_biasF from m_wblob / m_bias / m_condW / m_condB, asynchronously on `stream`
+    void buildFeatStream(hipStream_t stream) {
+        assert(m_nCond > 0);
+        const int L = m_numLayers;
+        const size_t wElems = (size_t)C::NW * CF::waveStreamFrags(L) * C::FRAG_ELEMS;
+        const int bTotal = L * C::BIAS_L + 2 * A;
+        if (!m_wblobF) {
+            gpuErrChk(hipMalloc(&m_wblobF, wElems * sizeof(elem)));
+            gpuErrChk(hipMalloc(&m_biasF, (size_t)bTotal * sizeof(float)));
+            std::vector<int2> map;
+            for (int l = 0; l < L; l++)
+                for (int i = 0; i < C::FLW; i++) map.push_back(make_int2((int)C::streamPos(l, i, L), (int)CF::streamPos(l, i, L)));
+            for (int q = 0; q < C::FHW; q++)
+                map.push_back(make_int2((int)C::headOffsetFrags(L) + C::headFrag(q), (int)CF::headOffsetFrags(L) + CF::headFrag(q)));
+            m_restreamN = (int)map.size();
+            gpuErrChk(hipMalloc(&m_restream, map.size() * sizeof(int2)));
+            gpuErrChk(hipMemcpy(m_restream, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice));
+        }
+        gpuErrChk(hipMemsetAsync(m_wblobF, 0, wElems * sizeof(elem), stream));
+        hipLaunchKernelGGL(wn::restream_kernel, dim3(gridFor((size_t)C::NW * m_restreamN * 64)), dim3(256), 0, stream, (wn::uintx4*)m_wblobF,
+                           (const wn::uintx4*)m_wblob, (const int2*)m_restream, m_restreamN, C::waveStreamFrags(L), CF::waveStreamFrags(L), C::NW);
+        gpuErrChk(hipGetLastError());
+        for (int l = 0; l < L; l++) {
+            hipLaunchKernelGGL((wn::pack_weight_kernel<F16>), dim3(gridFor((size_t)2 * R * KC)), dim3(256), 0, stream,
+                               m_wblobF + CF::streamPos(l, CF::O_COND, L) * C::FRAG_ELEMS, m_condW + (size_t)l * KC * 2 * R, 2 * R, KC, C::NW,
+                               CF::waveStreamFrags(L) * C::FRAG_ELEMS, R / 16);
+            gpuErrChk(hipGetLastError());
+        }
+        hipLaunchKernelGGL((wn::feat_bias_kernel<F16>), dim3(gridFor(bTotal)), dim3(256), 0, stream, m_biasF, m_bias, m_condB, L, R, C::BIAS_L,
+                           bTotal);
+        gpuErrChk(hipGetLastError());
+        m_featDirty = false;
+    }
     size_t ringElems() const { return (size_t)m_tiles * m_ringSlots * R * 16; }
     unsigned statusWord(int i) {
         unsigned s = 0;

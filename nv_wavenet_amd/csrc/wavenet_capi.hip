@@ -114,6 +114,63 @@ int nvw_set_conditioning_packed_n(nvw_engine* e, const void* frags, int num_samp
     return 1;
 }
 int nvw_cond_tiles(nvw_engine* e) { return e->condTiles(); }
+// ---- conditioning computed in the generation kernel from the upsampled features ------------------------------------------------
+static bool devicePtr(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+int nvw_max_cond_channels(void) { return wn::kCondChannelsMax; }
+int nvw_set_conditioning_weights(nvw_engine* e, const float* Wcond, const float* bcond, int n_cond) {
+    if (!e->setConditioningWeights(Wcond, bcond, n_cond)) {
+        fprintf(stderr, "nvw_set_conditioning_weights: %d feature channels; the kernels are built for 1..%d (use the Lh path)\n", n_cond,
+                wn::kCondChannelsMax);
+        return 0;
+    }
+    return 1;
+}
+int nvw_feature_fragments(nvw_engine* e) { return e->featureFragments(); }
+size_t nvw_feature_elems(nvw_engine* e, int num_samples) { return e->featureElems(num_samples); }
+static bool featArgsOk(nvw_engine* e, const char* who, const void* p, int first, int count) {
+    if (e->conditioningChannels() <= 0) {
+        fprintf(stderr, "%s: call nvw_set_conditioning_weights first\n", who);
+        return false;
+    }
+    if (!devicePtr(p)) {
+        fprintf(stderr, "%s: the features must be device memory\n", who);
+        return false;
+    }
+    if (first < 0 || count <= 0 || first + count > e->maxSamples()) {
+        fprintf(stderr, "%s: samples [%d, %d) outside the engine's %d\n", who, first, first + count, e->maxSamples());
+        return false;
+    }
+    return true;
+}
+int nvw_set_conditioning_features(nvw_engine* e, const void* frags, int num_samples, size_t elems) {
+    if (!featArgsOk(e, "nvw_set_conditioning_features", frags, 0, num_samples)) return 0;
+    if (elems < e->featureElems(num_samples)) {
+        fprintf(stderr, "nvw_set_conditioning_features: %zu elements cannot hold %d samples of feature fragments (%zu needed)\n", elems,
+                num_samples, e->featureElems(num_samples));
+        return 0;
+    }
+    e->setConditioningFeatures(frags, num_samples);
+    return 1;
+}
+int nvw_pack_features(nvw_engine* e, const void* x, int precision, long long b_stride, long long c_stride, long long t_stride,
+                      int first_sample, int count, void* stream) {
+    if (!featArgsOk(e, "nvw_pack_features", x, first_sample, count) || (precision != 32 && precision != 16)) return 0;
+    e->packFeatures(x, precision, b_stride, c_stride, t_stride, first_sample, count, (hipStream_t)stream);
+    return 1;
+}
+int nvw_set_features(nvw_engine* e, const void* x, int precision, long long b_stride, long long c_stride, long long t_stride,
+                     int num_samples) {
+    if (!featArgsOk(e, "nvw_set_features", x, 0, num_samples) || (precision != 32 && precision != 16)) return 0;
+    e->setFeatures(x, precision, b_stride, c_stride, t_stride, num_samples);
+    return 1;
+}
 void nvw_set_selectors(nvw_engine* e, float* sel, int num_samples) { e->setSelectors(sel, num_samples); }
 unsigned nvw_chain_status(nvw_engine* e) { return e->chainStatus(); }
 unsigned nvw_chain_fallbacks(nvw_engine* e) { return e->chainFallbacks(); }

@@ -9,6 +9,9 @@
 #ifndef WN_PFMAX
 #define WN_PFMAX 12          // wavenet_wg: largest depth of the per-wave weight prefetch ring (the divisor of a layer's stream <= this: 9)
 #endif
+#ifndef WN_PFMAX_FEAT
+#define WN_PFMAX_FEAT 12     // ... of the kernels that compute the conditioning themselves (a layer's stream is 24 fragments at C3: 12)
+#endif
 #ifndef WN_HEADREGS
 #define WN_HEADREGS 128      // wavenet_wg, one tile per workgroup: accumulator registers the resident A x A head matrix may take
 #endif
@@ -23,6 +26,9 @@
 #endif
 #ifndef WN_REQ_AT
 #define WN_REQ_AT 6          // wavenet_wg: eighths of the skip GEMM behind which taps and conditioning of layer l+2 are requested
+#endif
+#ifndef WN_REQ_AT_FEAT
+#define WN_REQ_AT_FEAT 4     // ... of the kernels that compute the conditioning: eighths of the (skip + conditioning) fragments under the gate
 #endif
 // cache-policy bits of the buffer instructions (0 = default, 2 = nt / streaming, 16 = sc1)
 #ifndef WN_W_AUX
@@ -39,6 +45,9 @@
 #endif
 #ifndef WN_RAW_AUX
 #define WN_RAW_AUX 0         // conditioning read in place from the caller's [N][L][B][2R] tensor
+#endif
+#ifndef WN_FEAT_AUX
+#define WN_FEAT_AUX 0        // upsampled features (in-kernel conditioning): every wave of a workgroup reads the same fragments
 #endif
 #ifndef WN_BC_LD_AUX
 #define WN_BC_LD_AUX " nt"   // wavenet_bcast: conditioning / tap loads (instruction modifier text)

@@ -98,7 +98,13 @@ constexpr int pick_pf(int fl, int pfmax) {
 }
 constexpr int align16(int x) { return (x + 15) & ~15; }
 
-template <bool F16, int R, int S, int A, int BT>
+// KFC > 0: the conditioning is COMPUTED in the kernel from the upsampled features (round 5; role of the model's `cond_layers` 1x1
+// convolution, pytorch/wavenet.py:190-202): every layer's part of a wave's stream then also carries Wcond[l] for this wave's gate
+// tiles, KFC k-fragments wide (the features of an utterance and sample, zero-padded to KFC * 16 * TPF channels).
+constexpr int kCondChannelsMax = 80;      // n_cond_channels of the reference's model (pytorch/config.json); fewer are zero-padded
+template <bool F16> constexpr int feat_kfc() { return (kCondChannelsMax + 16 * Prec<F16>::TPF - 1) / (16 * Prec<F16>::TPF); }
+
+template <bool F16, int R, int S, int A, int BT, int KFC = 0>
 struct Cfg {
     using P = Prec<F16>;
     static constexpr int TPF = P::TPF, EPL = P::EPL;
@@ -109,27 +115,30 @@ struct Cfg {
     static constexpr int THREADS = NW * 64;
     static constexpr int HTW = RT / NW, STW = ST / NW, ATW = AT / NW;   // tiles per wave
     static constexpr int KF_R = RT / TPF, KF_S = ST / TPF, KF_A = AT / TPF;
-    // fragments of one layer per wave, LOGICAL order: prev | cur | res | skip
-    static constexpr int FW_GATE = 2 * HTW * KF_R, FW_RES = HTW * KF_R, FW_SKIP = STW * KF_R;
-    static constexpr int O_PREV = 0, O_CUR = FW_GATE, O_RES = 2 * FW_GATE, O_SKIP = O_RES + FW_RES;
-    static constexpr int FLW = O_SKIP + FW_SKIP;
+    // fragments of one layer per wave, LOGICAL order: prev | cur | res | skip | cond
+    static constexpr int FW_GATE = 2 * HTW * KF_R, FW_RES = HTW * KF_R, FW_SKIP = STW * KF_R, FW_COND = 2 * HTW * KFC;
+    static constexpr int O_PREV = 0, O_CUR = FW_GATE, O_RES = 2 * FW_GATE, O_SKIP = O_RES + FW_RES, O_COND = O_SKIP + FW_SKIP;
+    static constexpr int FLW = O_COND + FW_COND;
     // PHYSICAL order of a wave's stream = the order wavenet_wg consumes it in:
-    //   cur(0) res(0) prev(1) | cur(1) skip(0) res(1) prev(2) | ... | cur(L-1) skip(L-2) res(L-1) prev(0) | skip(L-1) | head
-    // (the skip GEMM of a layer runs under the next layer's gate arithmetic, the dilated-tap GEMM of a layer in the
-    // exchange window at the end of the layer before; prev(0) at the end belongs to the NEXT sample).  The layers
-    // still take L*FLW fragments, and the part of layer l >= 1 starts FW_SKIP fragments before l*FLW.
+    //   cur(0) cond(1) res(0) prev(1) | cur(1) skip(0) cond(2) res(1) prev(2) | ... | cur(L-1) skip(L-2) cond(0) res(L-1) prev(0) |
+    //   skip(L-1) | head
+    // (the skip GEMM of a layer and the conditioning GEMM of the layer after run under the next layer's gate arithmetic, the
+    // dilated-tap GEMM of a layer in the exchange window at the end of the layer before; cond(0) prev(0) at the end belong to the
+    // NEXT sample; cond(.) is empty unless KFC > 0).  The layers still take L*FLW fragments, and the part of layer l >= 1 starts
+    // FW_SKIP fragments before l*FLW.
     // streamPos: logical fragment i of layer l -> position in the wave's stream.
     __host__ __device__ static constexpr size_t streamPos(int l, int i, int L) {
-        return i < O_CUR    ? (size_t)((l == 0 ? L : l) - 1) * FLW + FW_GATE + FW_RES + (i - O_PREV)
+        return i < O_CUR    ? (size_t)((l == 0 ? L : l) - 1) * FLW + FW_GATE + FW_COND + FW_RES + (i - O_PREV)
                : i < O_RES  ? (l == 0 ? (size_t)(i - O_CUR) : (size_t)l * FLW - FW_SKIP + (i - O_CUR))
-               : i < O_SKIP ? (size_t)l * FLW + FW_GATE + (i - O_RES)
-                            : (l == L - 1 ? (size_t)L * FLW - FW_SKIP + (i - O_SKIP)
-                                          : (size_t)(l + 1) * FLW - FW_SKIP + FW_GATE + (i - O_SKIP));
+               : i < O_SKIP ? (size_t)l * FLW + FW_GATE + FW_COND + (i - O_RES)
+               : i < O_COND ? (l == L - 1 ? (size_t)L * FLW - FW_SKIP + (i - O_SKIP)
+                                          : (size_t)(l + 1) * FLW - FW_SKIP + FW_GATE + (i - O_SKIP))
+                            : (size_t)((l == 0 ? L : l) - 1) * FLW + FW_GATE + (i - O_COND);
     }
     // the same places as seen from the kernel: relative to the start of the part of layer l-1 (= (l-1)*FLW, a whole
     // number of ring turns), so that position % PF is the ring slot
-    static constexpr int P_CUR0 = FLW, P_CUR = FLW - FW_SKIP, P_SKIP = P_CUR + FW_GATE, P_RES = FLW + FW_GATE,
-                         P_PREV = P_RES + FW_RES;
+    static constexpr int P_CUR0 = FLW, P_CUR = FLW - FW_SKIP, P_SKIP = P_CUR + FW_GATE, P_COND = FLW + FW_GATE,
+                         P_RES = P_COND + FW_COND, P_PREV = P_RES + FW_RES;
     // per-wave fragment stream of the head: zs | za
     static constexpr int FW_ZS = ATW * KF_S, FW_ZA = ATW * KF_A;
     static constexpr int FHW = FW_ZS + FW_ZA;
@@ -139,7 +148,7 @@ struct Cfg {
     // them in place) depth 9: 19.6 / 24.2 / 33.4 and depth 18 (a whole layer): 21.0 / 26.2 / 37.7 at batch
     // 16 / 4096 / 8192: a ring that does not divide the streamed head (32 fragments) is rotated once per sample,
     // and every such rotation -- like every register copy the compiler places on a loop edge -- drains the queue.
-    static constexpr int PF = pick_pf(FLW, WN_PFMAX);
+    static constexpr int PF = pick_pf(FLW, KFC > 0 ? WN_PFMAX_FEAT : WN_PFMAX);
     static_assert(FLW % PF == 0 && PF <= FW_ZS, "prefetch ring must divide the layer stream");
     // The head's weights (FHW fragments per wave) stay RESIDENT in registers for the whole launch
     // when they fit the otherwise idle accumulator half of the register file (4 regs/fragment):
@@ -232,8 +241,10 @@ struct Params {
     const void* cond;        // [sample][L][tile][wave][COND_FR] fragments
     const void* condRaw;     // or (RAW kernels) the caller's [sample][L][maxBatch][2R] tensor, read in place: fp32 (RAW = 1)
                              // or T_data = fp16 (RAW = 2, fp16 engine; the reference keeps m_Lh in T_data, nv_wavenet.cuh:326)
-    int condRawKind;         // 0: packed `cond`; 1: condRaw is fp32; 2: condRaw is fp16 (what the RAW template argument says, for
-                             // the kernels that choose at run time)
+    int condRawKind;         // 0: packed `cond`; 1: condRaw is fp32; 2: condRaw is fp16; 3: `feat` (what the RAW template argument says,
+                             // for the kernels that choose at run time)
+    const void* feat;        // RAW = 3: upsampled features as B fragments, [sample][tile][KFC] fragments (T_data; condSamples samples);
+                             // wblob / bias then are the stream WITH the conditioning weights and the gate biases + bcond
     const unsigned* gate;    // when non-NULL: the launch does nothing unless *gate != 0 (fallback behind a wavenet_chain launch)
     const float* sel;        // [N][maxBatch] uniform draws
     void* ring;              // [tile][ringSlots][KF_R] fragments
@@ -584,7 +595,8 @@ WN_DEV void refill_group(WStream<F16, PF, PIN>& ws, rsrc_t rs, int idx, int base
 #endif
 }
 // acc[bt][mt] += W(tile mt) * b[bt]   (fragment order as in gemm())
-template <bool F16, int PF, int WRAP, int BT, int MT, int KF, bool PIN>
+// BPIN: the B operands live in the accumulator file as well (agpr_pin; the per-sample feature fragments of the in-kernel conditioning)
+template <bool F16, int PF, int WRAP, int BT, int MT, int KF, bool PIN, bool BPIN = false>
 WN_DEV void gemm_b(WStream<F16, PF, PIN>& ws, rsrc_t rs, int pos0, int basePos, int wrapPos, unsigned laneOff,
                    floatx4 (&acc)[BT][MT], const typename Prec<F16>::frag (&b)[BT][KF]) {
     constexpr int G = MT >= 4 ? 4 : MT;
@@ -608,7 +620,7 @@ WN_DEV void gemm_b(WStream<F16, PF, PIN>& ws, rsrc_t rs, int pos0, int basePos, 
                 for (int mi = 0; mi < TG; mi++)
 #pragma unroll
                     for (int bt = 0; bt < BT; bt++)
-                        acc[bt][mg * G + m0 + mi] = mma(a[mi], b[bt][kf], acc[bt][mg * G + m0 + mi]);
+                        acc[bt][mg * G + m0 + mi] = mma(a[mi], agpr_operand<BPIN>(b[bt][kf]), acc[bt][mg * G + m0 + mi]);
                 if (!EARLY || (mg == MT / G - 1 && kf == KF - 1 && m0 + TG >= G)) refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, idx, basePos, wrapPos, laneOff);
             }
         }
@@ -827,9 +839,15 @@ template <bool F16, int RAW, int CR> WN_DEV typename Prec<F16>::frag cond_frag(c
 // T_data, nv_wavenet.cuh:326); each lane loads the 4 consecutive channels of its utterance per gate tile (16 / 8 bytes) and, in
 // the fp16 engine, scales and rounds them exactly as pack_cond_tiled_kernel would have, so packed and in-place runs are
 // bit-identical (for an fp16 tensor: identical to packing its values).
+// RAW = 3: the conditioning is computed HERE from the upsampled features (Params::feat; role of the model's cond_layers,
+// pytorch/wavenet.py:190-202): Lh[t][l] = Wcond[l] c[t] + bcond[l] as KFC more k steps of the gate GEMM, their weights in the
+// wave's stream (Cfg<.., KFC>), their B operands -- KFC fragments per tile, 160 B per utterance instead of 2R * L values --
+// loaded once per sample.  Summation order of the gate pre-activation: (Bh + bcond), Wcond c, dilated tap, current tap.
 template <bool F16, int R, int S, int A, int BT, bool EMBLDS, bool DUMP = true, int RAW = 0>
 __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_wg(const Params p) {
-    using C = Cfg<F16, R, S, A, BT>;
+    constexpr bool FEAT = RAW == 3;
+    constexpr int KFC = FEAT ? feat_kfc<F16>() : 0;
+    using C = Cfg<F16, R, S, A, BT, KFC>;
     using P = Prec<F16>;
     using frag = typename P::frag;
     using quad = typename P::quad;
@@ -848,7 +866,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     char* const xpbuf = lds + C::OFF_XP;
     float* const biasLds = (float*)(lds + C::LDS_FIXED);
 
-    static_assert(RAW == 0 || RAW == 1 || (RAW == 2 && F16), "RAW: 0 packed, 1 fp32 in place, 2 fp16 in place (fp16 engine)");
+    static_assert(RAW == 0 || RAW == 1 || (RAW == 2 && F16) || RAW == 3, "RAW: 0 packed, 1 fp32 in place, 2 fp16 in place (fp16 engine), 3 features");
     if (p.gate != nullptr && __builtin_nontemporal_load(p.gate) == 0u) return;   // (a fallback launch that is not needed)
 
     const int tid = threadIdx.x;
@@ -952,7 +970,23 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     frag xpA[BT][XPW], xpB[BT][XPW];            // layers of even / odd parity
     // conditioning registers per tile: COND_FR packed fragments, or (fp16, in-place) one fp32 quad per gate tile
     constexpr int CR = (RAW == 1 && F16) ? 2 * C::COND_FR : C::COND_FR;
-    frag cdA[BT][CR], cdB[BT][CR];
+    frag cdA[BT][CR], cdB[BT][CR];      // (unused when the conditioning is computed here: FEAT)
+    // FEAT: the feature fragments of the sample being generated (cfCur) and of the next one (cfNext): the conditioning GEMM at
+    // the end of the last layer belongs to layer 0 of the NEXT sample, so cfNext moves into cfCur behind the last-but-one
+    // layer's conditioning GEMM and is requested again (sample t+2) behind the layer loop -- a whole sample ahead of its use
+    constexpr int KFCR = FEAT ? KFC : 1;
+    frag cfCur[BT][KFCR], cfNext[BT][KFCR];
+    const size_t featStride = (size_t)p.tiles * KFC * 1024;                          // one sample of features
+    const char* const featMine = (const char*)p.feat + (size_t)tile0 * KFC * 1024;
+    auto load_feat = [&](int tn, frag (&dst)[BT][KFCR]) {
+        const int tc = tn < p.condSamples ? tn : p.condSamples - 1;                  // (the read-ahead past the last sample is never used)
+        const rsrc_t rsF = make_rsrc(featMine + (size_t)tc * featStride);
+#pragma unroll
+        for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+            for (int k = 0; k < KFC; k++)
+                dst[bt][k] = buf_load<frag, WN_FEAT_AUX>(rsF, laneOff + (unsigned)(k & 3) * 1024u, (unsigned)((bt * KFC + (k & ~3)) * 1024));
+    };
     // per-(sample,layer) strides in bytes; everything here is wave-uniform (SALU)
     const size_t condStride = (size_t)p.tiles * NW * C::COND_FR * 1024;            // one (sample,layer) row
     const char* const condMine = (const char*)p.cond + ((size_t)tile0 * NW + w) * C::COND_FR * 1024;
@@ -1013,7 +1047,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 for (int e = 0; e < P::EPL; e++) xd[bt][i][e] = (elem)(float)(tn + i);
 #endif
 #ifndef WN_ABL_NOCOND
-            if constexpr (RAW != 0) {
+            if constexpr (FEAT) {
+                // nothing to load per layer
+            } else if constexpr (RAW != 0) {
                 // gate slot it = 0 .. 2*HTW-1 -> tile w + NW*(it>>1) (+RT for the sigmoid half): 4 channels of this lane's utterance
                 const int tc = tn < p.condSamples ? tn : p.condSamples - 1;      // (the read-ahead past the last sample is never used)
                 const rsrc_t rsRaw = make_rsrc((const char*)p.condRaw + ((size_t)tc * L + ln) * rawRow);
@@ -1108,7 +1144,15 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 acc[bt][2 * i + 1] = *(const floatx4*)(biasLds + (w + NW * i + RT) * 16 + g * 4);
             }
         }
-        if constexpr (F16) {
+        if constexpr (FEAT) {
+            load_feat(p.initSample, cfNext);
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int k = 0; k < KFC; k++) cfCur[bt][k] = agpr_operand<F16>(cfNext[bt][k]);
+            gemm_direct<F16, BT, 2 * HTW, KFC>(wbase + C::streamPos(0, C::O_COND, L) * 1024, laneOff, acc, cfCur);
+            load_feat(p.initSample + 1, cfNext);
+        } else if constexpr (F16) {
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
@@ -1226,7 +1270,87 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 
             // gate -> h tiles of this wave -> LDS, in stages (pairs of values: exp2 a | exp2 b | rcp | rcp | product)
             // with the MFMAs of the previous layer's skip GEMM in between:  skip <- Wskip h + skip
-            {
+            // FEAT: ... and behind them the conditioning GEMM of the NEXT layer, accN <- (Bh + bcond) + Wcond c, likewise MFMA by MFMA
+            // under the gate: the matrix core is idle there and nothing of it is on the dependent chain (at the end of the layer,
+            // where the packed conditioning is added, 6 k-steps per tile sit between the x stores and the x barrier: 540 clk per
+            // layer at three tiles, measured)
+            floatx4 accN[FEAT ? BT : 1][2 * HTW];
+            if constexpr (FEAT) {
+#pragma unroll
+                for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                    for (int i = 0; i < HTW; i++) {
+                        accN[bt][2 * i] = *(const floatx4*)(blN + (w + NW * i) * 16 + g * 4);
+                        accN[bt][2 * i + 1] = *(const floatx4*)(blN + (w + NW * i + RT) * 16 + g * 4);
+                    }
+            }
+            if constexpr (FEAT) {
+                constexpr int NS = BT * HTW * 2 * 5;                          // gate stages
+                constexpr int NFS = SKIP ? STW * KF_R : 0, NFC = C::FW_COND;   // fragments: skip, then cond
+                constexpr int NM = (NFS + NFC) * BT;                           // MFMA slots
+                constexpr int G0S = STW >= 4 ? 4 : STW, G0C = 2 * HTW >= 4 ? 4 : 2 * HTW;     // (fragment order inside a GEMM: see gemm_b)
+                constexpr bool EARLY = PF > 1;      // (see gemm_b; a one-deep ring refills its only slot right behind its MFMAs)
+                floatx2 ea, eb, ra, rb, hp;
+                floatx4 hv;
+                auto stage = [&](auto SI) {
+                    constexpr int s = decltype(SI)::value, pr = s / 5, st = s % 5;
+                    constexpr int bt = pr / (2 * HTW), i = (pr / 2) % HTW, r = (pr & 1) * 2;
+                    gate_stage<F16, st>(acc[bt][2 * i][r], acc[bt][2 * i][r + 1], acc[bt][2 * i + 1][r], acc[bt][2 * i + 1][r + 1],
+                                        ea, eb, ra, rb, hp);
+                    if constexpr (st == 4) {
+                        hv[r] = hp[0];
+                        hv[r + 1] = hp[1];
+                        if constexpr (r == 2) lds_put_tile<F16>(hbuf + bt * KF_R * 1024, w + NW * i, lane, hv);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                static_for<NFS + NFC>([&](auto FI) {
+                    constexpr int fi = decltype(FI)::value;
+                    constexpr bool isSkip = fi < NFS;
+                    constexpr int q = isSkip ? fi : fi - NFS, G0 = isSkip ? G0S : G0C, KFq = isSkip ? KF_R : KFC;
+                    constexpr int kf = (q / G0) % KFq, mt = (q / (G0 * KFq)) * G0 + q % G0;
+                    constexpr int pos = isSkip ? C::P_SKIP + q : C::P_COND - PB + q;
+                    constexpr int posPrev = (fi - 1 < NFS) ? C::P_SKIP + fi - 1 : C::P_COND - PB + fi - 1 - NFS;
+                    frag a[1];
+                    take_group<F16, PF, ws_pin, 1>(ws, pos, a);
+                    if constexpr (EARLY && fi > 0) refill_group<F16, PF, 0, ws_pin, 1>(ws, rsW, posPrev, wl, 0, laneOff);
+                    static_for<BT>([&](auto BI) {
+                        constexpr int bt = decltype(BI)::value, m = fi * BT + bt;
+                        if constexpr (isSkip) skip[bt][mt] = mma(a[0], hb[bt][kf], skip[bt][mt]);
+                        else accN[bt][mt] = mma(a[0], cfCur[bt][kf], accN[bt][mt]);      // (cfCur: accumulator-file values, pinned where they are made)
+                        __builtin_amdgcn_sched_barrier(0);
+                        static_for_range<m * NS / NM, (m + 1) * NS / NM>(stage);
+                    });
+                    if constexpr (!EARLY || fi == NFS + NFC - 1) refill_group<F16, PF, 0, ws_pin, 1>(ws, rsW, pos, wl, 0, laneOff);
+                    // dilated tap of layer l+2 (HBM) into the register set this layer has finished with (see the packed path below)
+                    if constexpr (SKIP && fi == (NFS + NFC) * WN_REQ_AT_FEAT / 8) {
+                        prefetch(t, l + 2, dl2, xpC, cdC);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                if (l == L - 2) {
+                    asm volatile("");                  // (keeps this a branch)
+                    // pinned HERE, once per sample (agpr_pin ties its result to its operand's registers: applied at every use of a
+                    // value that lives on, it costs a copy of the fragment per use -- 150 instructions per layer, measured)
+#pragma unroll
+                    for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                        for (int k = 0; k < KFC; k++) cfCur[bt][k] = agpr_operand<F16>(cfNext[bt][k]);
+                }
+                if constexpr (SKIP) {
+                    if (dumpNow) {
+                        const float* bp = biasLds + (l - 1) * C::BIAS_L + 3 * R;   // running bias sum
+#pragma unroll
+                        for (int bt = 0; bt < BT; bt++) {
+                            if (!uvalid[bt]) continue;
+#pragma unroll
+                            for (int i = 0; i < STW; i++)
+                                *(floatx4*)(p.skipOut + ((size_t)(l - 1) * p.maxBatch + ub[bt]) * S + (w + NW * i) * 16 + g * 4) =
+                                    skip[bt][i] + *(const floatx4*)(bp + (w + NW * i) * 16 + g * 4);
+                        }
+                    }
+                }
+            } else {
                 constexpr int NS = BT * HTW * 2 * 5;                  // gate stages
                 constexpr int NM = SKIP ? STW * KF_R * BT : 0;        // MFMA slots
                 floatx2 ea, eb, ra, rb, hp;
@@ -1299,13 +1423,18 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
                 for (int i = 0; i < HTW; i++)
                     xa[bt][i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[bt][i];
-            // the next layer's accumulators start at its gate bias
+            // the next layer's accumulators start at its gate bias (FEAT: + its conditioning, formed under the gate above)
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
                 for (int i = 0; i < HTW; i++) {
-                    acc[bt][2 * i] = *(const floatx4*)(blN + (w + NW * i) * 16 + g * 4);
-                    acc[bt][2 * i + 1] = *(const floatx4*)(blN + (w + NW * i + RT) * 16 + g * 4);
+                    if constexpr (FEAT) {
+                        acc[bt][2 * i] = accN[bt][2 * i];
+                        acc[bt][2 * i + 1] = accN[bt][2 * i + 1];
+                    } else {
+                        acc[bt][2 * i] = *(const floatx4*)(blN + (w + NW * i) * 16 + g * 4);
+                        acc[bt][2 * i + 1] = *(const floatx4*)(blN + (w + NW * i + RT) * 16 + g * 4);
+                    }
                 }
 
             // residual: x <- Wres h + Bres + x  (this wave's tiles) -> LDS
@@ -1326,7 +1455,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             // every organisation of the engine: bias, conditioning, dilated tap, current tap).  fp16: a fragment in B
             // layout already, added by the matrix core through a 0/1 selection matrix (2 MFMAs instead of 8
             // conversions + 8 adds per fragment)
-            if constexpr (F16) {
+            if constexpr (FEAT) {
+                // (computed under the gate above)
+            } else if constexpr (F16) {
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++)
 #pragma unroll
@@ -1404,6 +1535,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 }
             }
         }
+        if constexpr (FEAT) load_feat(t + 2, cfNext);      // (its last reader was the move behind layer L-2)
         // skip GEMM of the last layer
         gemm_b<F16, PF, 0, BT, STW, KF_R>(ws, rsW, C::P_CUR, (L - 1) * FLW, 0, laneOff, skip, hb);
 
@@ -1697,6 +1829,75 @@ __global__ __launch_bounds__(256) void pack_cond_tiled_kernel(typename Prec<F16>
                 }
             }
             __builtin_nontemporal_store(o, (frag*)(d + (size_t)pi * EPL));
+        }
+        __syncthreads();
+    }
+}
+
+// ---- in-kernel conditioning (RAW = 3): setup kernels -----------------------------------------------------------------------
+// The model's conditioning convolution weight, [L][2R][nCond] (= cond_layers.weight [2R*L][nCond][1], pytorch/wavenet.py:73-74),
+// -> per layer col-major [KC][2R] fp32, zero-padded to KC channels: what pack_weight_kernel takes
+static __global__ void cond_weight_arrange_kernel(float* __restrict__ dst, const float* __restrict__ src, int L, int R2, int nCond, int KC) {
+    const size_t n = (size_t)L * R2 * nCond;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nCond), r = (int)((i / nCond) % R2), l = (int)(i / ((size_t)nCond * R2));
+        dst[((size_t)l * KC + c) * R2 + r] = src[i];
+    }
+}
+// fragments of the plain stream -> their places in the stream that also carries the conditioning weights (map: {from, to} per fragment
+// of ONE wave's stream; the same for every wave)
+static __global__ void restream_kernel(uintx4* __restrict__ dst, const uintx4* __restrict__ src, const int2* __restrict__ map, int nmap,
+                                       size_t srcWaveFrags, size_t dstWaveFrags, int NW) {
+    const size_t n = (size_t)NW * nmap * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), m = (int)((i >> 6) % nmap), w = (int)((i >> 6) / nmap);
+        dst[((size_t)w * dstWaveFrags + map[m].y) * 64 + lane] = src[((size_t)w * srcWaveFrags + map[m].x) * 64 + lane];
+    }
+}
+// bias table of that stream: the plain one with bcond (pre-scaled like Bh) added to the gate biases
+template <bool F16>
+__global__ void feat_bias_kernel(float* __restrict__ dst, const float* __restrict__ bias, const float* __restrict__ bcond, int L, int R,
+                                 int biasL, int total) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        float v = bias[i];
+        const int l = i / biasL, k = i % biasL;
+        if (l < L && k < 2 * R) v += bcond[l * 2 * R + k] * gate_prescale<F16>(k >= R);
+        dst[i] = v;
+    }
+}
+// Upsampled features of any strided [utterance][channel][sample] tensor (fp32 or fp16 elements) -> B fragments
+//   dst [sample][tiles][KFC][64 lanes][EPL]: fragment kf, lane (g, j), element e = channel (kf*TPF + (e>>2))*16 + 4g + (e&3) of
+//   utterance tile*16 + j; channels >= nCond and utterances >= batch are zero.
+// One workgroup per (tile, TB samples): gathered into an LDS image of the fragments, written as 16-byte pieces.
+template <bool F16>
+__global__ __launch_bounds__(256) void pack_features_kernel(typename Prec<F16>::elem* __restrict__ dst, const void* __restrict__ src, int srcBits,
+                                                            long long bS, long long cS, long long tS, int nCond, int batch, int count,
+                                                            int tiles, int tilesUsed) {
+    using elem = typename Prec<F16>::elem;
+    constexpr int KFC = feat_kfc<F16>(), TPF = Prec<F16>::TPF, EPL = Prec<F16>::EPL, KC = KFC * 16 * TPF, TB = 8;
+    __shared__ __attribute__((aligned(16))) elem img[TB * KFC * 64 * EPL];
+    const int tblocks = (count + TB - 1) / TB;
+    const size_t nblk = (size_t)tilesUsed * tblocks;
+    for (size_t bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const int tile = (int)(bi % tilesUsed), t0 = (int)(bi / tilesUsed) * TB;
+        for (int i = threadIdx.x; i < 16 * KC * TB; i += 256) {
+            int j, c, tt;
+            if (tS == 1) { tt = i % TB; c = (i / TB) % KC; j = i / (TB * KC); }      // (the contiguous axis of the source innermost)
+            else { c = i % KC; j = (i / KC) % 16; tt = i / (KC * 16); }
+            const int b = tile * 16 + j, t = t0 + tt;
+            float v = 0.f;
+            if (c < nCond && b < batch && t < count) {
+                const long long at = b * bS + c * cS + t * tS;
+                v = srcBits == 16 ? (float)((const _Float16*)src)[at] : ((const float*)src)[at];
+            }
+            const int kf = c / (16 * TPF), tk = (c / 16) % TPF, g = (c % 16) / 4, r = c % 4;
+            img[((tt * KFC + kf) * 64 + g * 16 + j) * EPL + tk * 4 + r] = (elem)v;
+        }
+        __syncthreads();
+        for (int pi = threadIdx.x; pi < TB * KFC * 64; pi += 256) {
+            const int tt = pi / (KFC * 64), rem = pi % (KFC * 64);
+            if (t0 + tt < count)
+                *(uintx4*)(dst + (((size_t)(t0 + tt) * tiles + tile) * KFC * 64 + rem) * EPL) = *(const uintx4*)(img + (size_t)pi * EPL);
         }
         __syncthreads();
     }

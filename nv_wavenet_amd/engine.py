@@ -64,8 +64,8 @@ class WavenetEngine:
         self.precision = precision
         if isinstance(organisation, str) or organisation is None:
             organisation = Org.BY_NAME[organisation]
-        if organisation not in range(10):
-            raise ValueError("organisation must be 0..9")
+        if organisation not in range(max(v for v in Org.BY_NAME.values()) + 1):
+            raise ValueError("organisation must be 0..%d" % max(v for v in Org.BY_NAME.values()))
         self._h = lib.nvw_create_ex(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
                                     1 if tanhEmbed else 0, organisation)
         if not self._h:
@@ -154,6 +154,57 @@ class WavenetEngine:
         self._cond_keep = frags
         if not lib.nvw_set_conditioning_packed_n(self._h, addr(frags), ns, frags.numel()):
             raise ValueError("the fragment tensor is too small for %d samples" % ns)
+
+    # ---- conditioning computed in the generation kernel from the upsampled features (include/nv_wavenet_c.h, round 5) ----------
+    def setConditioningWeights(self, Wcond, bcond):
+        """The model's `cond_layers` 1x1 convolution (pytorch/wavenet.py:73-74): Wcond [2R*L][n_cond] (or [2R*L][n_cond][1], or
+        [L][2R][n_cond]), bcond [2R*L]; fp32, numpy or torch, host or device; copied."""
+        W, b = _f32(Wcond), _f32(bcond)
+        nW = W.numel() if hasattr(W, "numel") else W.size
+        nb = b.numel() if hasattr(b, "numel") else b.size
+        assert nb == self.numLayers * 2 * self.R and nW % nb == 0, "Wcond / bcond do not match L x 2R"
+        self.nCond = nW // nb
+        if not lib.nvw_set_conditioning_weights(self._h, addr(W), addr(b), self.nCond):
+            raise ValueError("%d feature channels: the kernels are built for 1..%d" % (self.nCond, lib.nvw_max_cond_channels()))
+
+    def featureFragments(self):
+        return int(lib.nvw_feature_fragments(self._h))
+
+    @staticmethod
+    def _feat_args(x):
+        import torch
+        assert hasattr(x, "data_ptr") and x.is_cuda and x.dim() == 3, "features: a CUDA tensor [batch][n_cond][samples] (any strides)"
+        bits = {torch.float32: 32, torch.float16: 16}.get(x.dtype)
+        assert bits, "features must be float32 or float16"
+        return bits, x.stride(0), x.stride(1), x.stride(2)
+
+    def setFeatures(self, x, numSamples=None):
+        """The upsampled features of the whole utterance: CUDA tensor [maxBatch][n_cond][numSamples] (the model's upsample
+        output; any strides, e.g. a channels-last tensor transposed).  Copied into fragment order; resets the history."""
+        bits, sb, sc, st = self._feat_args(x)
+        ns = x.size(2) if numSamples is None else int(numSamples)
+        assert x.size(0) == self.maxBatch and x.size(1) == self.nCond and x.size(2) >= ns
+        self._cond_keep = None
+        assert lib.nvw_set_features(self._h, x.data_ptr(), bits, sb, sc, st, ns)
+
+    def packFeatures(self, x, firstSample, stream=None):
+        """Samples [firstSample, firstSample + x.size(2)) of the features, asynchronously on `stream`; history untouched."""
+        bits, sb, sc, st = self._feat_args(x)
+        assert x.size(0) == self.maxBatch and x.size(1) == self.nCond
+        self._cond_keep = None
+        assert lib.nvw_pack_features(self._h, x.data_ptr(), bits, sb, sc, st, int(firstSample), x.size(2), stream)
+
+    def setConditioningFeatures(self, frags, numSamples=None):
+        """Features already in fragment order: CUDA tensor [numSamples][condTiles()][featureFragments()][64][8 fp16 | 4 fp32] of the
+        engine's T_data (nv_wavenet.py:feature_fragments builds it); used in place."""
+        import torch
+        assert hasattr(frags, "data_ptr") and frags.is_cuda and frags.is_contiguous()
+        want = torch.float16 if self.precision == 16 else torch.float32
+        assert frags.dtype == want, "an fp%d engine reads %s fragments" % (self.precision, want)
+        ns = frags.size(0) if numSamples is None else int(numSamples)
+        self._cond_keep = frags
+        if not lib.nvw_set_conditioning_features(self._h, addr(frags), ns, frags.numel()):
+            raise ValueError("the feature fragment tensor does not fit %d samples" % ns)
 
     def setSelectors(self, outputSelectors, numSamples=None):
         """The selector half of setInputs: [numSamples][maxBatch] uniform draws; conditioning and history untouched."""

@@ -205,6 +205,34 @@ def produce_cond_packed(x_channels_last, wfrag, bias, out, tiles):
     return out
 
 
+def feature_fragments(x, tiles, precision=16):
+    """Upsampled features x [B][n_cond][N] (any float dtype) -> the B-fragment order the generation kernels read
+    (WavenetEngine.setConditioningFeatures): [N][tiles][KFC][4 g][16 j][EPL], fragment kf, lane (g, j), element e = channel
+    (kf*TPF + (e>>2))*16 + 4g + (e&3) of utterance tile*16 + j, zero beyond n_cond / the batch.  (What pack_features_kernel writes.)"""
+    B, Cn, N = x.shape
+    TPF, EPL = (2, 8) if precision == 16 else (1, 4)
+    KFC = -(-80 // (16 * TPF))
+    KC = KFC * 16 * TPF
+    assert Cn <= 80
+    dtype = torch.float16 if precision == 16 else torch.float32
+    buf = torch.zeros(tiles * 16, KC, N, dtype=dtype, device=x.device)
+    buf[:B, :Cn] = x.to(dtype)
+    buf = buf.view(tiles, 16, KFC, TPF, 4, 4, N)                      # [tile][j][kf][tk][g][r][n]
+    return buf.permute(6, 0, 2, 4, 1, 3, 5).reshape(N, tiles, KFC, 4, 16, EPL).contiguous()
+
+
+def upsample_features(features, upsample_weight, upsample_bias, upsample_stride, via_gemm=None):
+    """The upsampling half of WaveNet.get_cond_input (pytorch/wavenet.py:195-197): ConvTranspose1d + trimming of its tail.
+    Returns [B][n_cond][N] (a transposed view of the channels-last product on the GPU)."""
+    import torch.nn.functional as F
+    gemm = features.is_cuda if via_gemm is None else via_gemm
+    if gemm and upsample_weight.size(2) % upsample_stride == 0:
+        return _upsample_trimmed_gemm(features, upsample_weight, upsample_bias, upsample_stride).transpose(1, 2)
+    x = F.conv_transpose1d(features, upsample_weight, upsample_bias, stride=upsample_stride)
+    cutoff = upsample_weight.size(2) - upsample_stride
+    return x[:, :, :-cutoff] if cutoff > 0 else x
+
+
 def _upsample_trimmed_gemm(features, weight, bias, stride, pad_to=1):
     """ConvTranspose1d(kernel = m * stride, stride) followed by the trimming of its (kernel - stride) tail, as m matrix products
     (one per stride-long segment of the kernel, over the frames whose contribution survives the trimming):
@@ -399,6 +427,23 @@ class NVWaveNetEngine(NVWaveNet):
         stream.synchronize()                # (the engine's own uploads run on its upload stream)
         # consumed in place from this tensor: no packed copy; it stays referenced until the run below has completed
         e.setConditioningDirect(cond_input, sample_count)
+        return self._generate(e, dev, stream, sample_count, batch_size, seed, return_audio, generator)
+
+    def infer_features(self, x, cond_weight, cond_bias, implementation=Impl.AUTO, seed=None, return_audio=False, generator=None):
+        """Generation with the conditioning convolution INSIDE the kernel (round 5): x = the upsampled features [batch][n_cond][samples]
+        on the GPU (upsample_features(...) / the model's self.upsample output, trimmed), cond_weight / cond_bias = the model's
+        cond_layers.weight / .bias.  Equivalent to infer(model.get_cond_input(features)) without ever building the
+        2R x batch x layers x samples tensor."""
+        batch_size, sample_count = x.size(0), x.size(2)
+        e = self._engine(batch_size, sample_count, implementation)
+        dev = x.device
+        key = (cond_weight.data_ptr(), cond_weight._version, cond_bias.data_ptr(), cond_bias._version)
+        if getattr(e, "_cond_w_key", None) != key:
+            e.setConditioningWeights(cond_weight.float().contiguous(), cond_bias.float().contiguous())
+            e._cond_w_key = key
+        stream = torch.cuda.current_stream(dev)
+        stream.synchronize()
+        e.setFeatures(x, sample_count)
         return self._generate(e, dev, stream, sample_count, batch_size, seed, return_audio, generator)
 
     def _infer_packed(self, frags, batch_size, implementation, seed, return_audio, generator):

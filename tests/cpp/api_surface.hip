@@ -59,12 +59,23 @@ template <typename C> constexpr bool stream_layout_ok(int L) {
         if (hits != 1) return false;
     }
     return C::streamPos(0, C::O_CUR, L) == 0 && C::streamPos(L - 1, C::O_SKIP + C::FW_SKIP - 1, L) == (size_t)n - 1 &&
-           C::streamPos(0, C::O_PREV, L) == (size_t)(L - 1) * C::FLW + C::FW_GATE + C::FW_RES;
+           C::streamPos(0, C::O_PREV, L) == (size_t)(L - 1) * C::FLW + C::FW_GATE + C::FW_RES + C::FW_COND &&
+           // consumption order of wavenet_wg inside layer l >= 1's part: cur(l) skip(l-1) cond(l+1) res(l) prev(l+1)
+           (L < 3 || (C::streamPos(1, C::O_CUR, L) + C::FW_GATE == C::streamPos(0, C::O_SKIP, L) &&
+                      C::streamPos(0, C::O_SKIP, L) + C::FW_SKIP + C::FW_COND == C::streamPos(1, C::O_RES, L) &&
+                      C::streamPos(1, C::O_RES, L) + C::FW_RES == C::streamPos(2, C::O_PREV, L) &&
+                      (C::FW_COND == 0 || C::streamPos(0, C::O_SKIP, L) + C::FW_SKIP == C::streamPos(2, C::O_COND, L)))) &&
+           (C::FW_COND == 0 || (C::streamPos(1, C::O_COND, L) == (size_t)C::FW_GATE && C::streamPos(0, C::O_RES, L) == (size_t)C::FW_GATE + C::FW_COND));
 }
 static_assert(stream_layout_ok<wn::Cfg<true, 64, 256, 256, 1>>(2) && stream_layout_ok<wn::Cfg<true, 64, 256, 256, 3>>(3) &&
                   stream_layout_ok<wn::Cfg<true, 64, 256, 256, 2>>(20) && stream_layout_ok<wn::Cfg<false, 32, 256, 256, 1>>(6) &&
                   stream_layout_ok<wn::Cfg<true, 128, 256, 256, 1>>(7),
               "Cfg::streamPos is not a permutation of the layer fragments");
+// ... and with the conditioning weights in the stream (in-kernel conditioning: KFC k-fragments per gate tile)
+static_assert(stream_layout_ok<wn::Cfg<true, 64, 256, 256, 3, wn::feat_kfc<true>()>>(5) && stream_layout_ok<wn::Cfg<true, 64, 256, 256, 1, 3>>(2) &&
+                  stream_layout_ok<wn::Cfg<false, 32, 128, 256, 1, wn::feat_kfc<false>()>>(3) && stream_layout_ok<wn::Cfg<true, 128, 256, 256, 1, 3>>(3) &&
+                  wn::Cfg<true, 64, 256, 256, 3, 3>::FLW == 24 && wn::feat_kfc<true>() == 3 && wn::feat_kfc<false>() == 5,
+              "Cfg<.., KFC>::streamPos is not a permutation of the layer fragments");
 
 int main() {
     bool ok = drive<float, float, 64, 128, 256>(4, 4, 16, 1);      // the default R,S,A of the class template
