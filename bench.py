@@ -174,15 +174,17 @@ STEADY_FROM = 640
 COND_BLOCK = 64                               # samples per reused fp32 source block of synthetic conditioning
 
 
-def steady_engine(w, B, n_timed, seed=11, in_place=None, organisation=0):
+def steady_engine(w, B, n_timed, seed=11, in_place=None, organisation=0, sh=None, impl=0):
     """Engine at batch B with samples 0 .. STEADY_FROM-1 behind it.  in_place: None = conditioning packed (chunk-wise from
     one reused COND_BLOCK-sample fp32 block: the packed copy of STEADY_FROM + n_timed samples is what stays in HBM, 5 120 B
     per utterance and sample), or torch.float32 / torch.float16 = a full [N][L][B][2R] tensor of that type consumed in
     place.  Returns (engine, total samples, keep-alive)."""
     import torch
     N = STEADY_FROM + n_timed
-    e = build_engine(w, B, N, organisation=organisation)
-    block, _ = device_inputs(B, COND_BLOCK, seed)
+    sh = sh or HEAD                           # (shapes other than the headline's: packed conditioning only)
+    assert sh is HEAD or in_place is None
+    e = build_engine(w, B, N, sh=sh, organisation=organisation, impl=impl)
+    block, _ = device_inputs(B, COND_BLOCK, seed, sh=sh)
     e.setSelectorSeed(seed)
     keep = None
     if in_place is None:
@@ -236,10 +238,10 @@ def time_range(e, first, count, N, B, reps=1):
     return a.elapsed_time(b) / reps
 
 
-def measure_steady_khz(w, B, n_timed=512, seed=11, in_place=None, organisation=0):
+def measure_steady_khz(w, B, n_timed=512, seed=11, in_place=None, organisation=0, sh=None, impl=0):
     """per-utterance kHz over samples STEADY_FROM .. STEADY_FROM + n_timed - 1 (all taps live, all rings wrapped)"""
     import torch
-    e, N, keep = steady_engine(w, B, n_timed, seed, in_place, organisation)
+    e, N, keep = steady_engine(w, B, n_timed, seed, in_place, organisation, sh, impl)
     ms = time_range(e, STEADY_FROM, n_timed, N, B)
     info = e.kernelInfo(B, False)
     ok = e.chainStatus() == 0
@@ -261,6 +263,7 @@ def reference_definition_khz(sh, impl, N=16384, chunk=2048):
     e.run(min(N, 64), sh.B)                    # warm-up (code objects, clocks)
     e.synchronize()
     e.setInputs(Lh, sel)
+    e.setClockProbe(True)
     del Lh
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -268,11 +271,12 @@ def reference_definition_khz(sh, impl, N=16384, chunk=2048):
     e.synchronize()
     ms = 1e3 * (time.perf_counter() - t0)
     info = e.kernelInfo(sh.B, False)
+    ghz = e.lastLaunchClockGHz()
     ok = ok and e.chainStatus() == 0 and int(y.min()) >= 0 and int(y.max()) < sh.A and int(torch.unique(y).numel()) > 8
     e.close()
     torch.cuda.empty_cache()
     return {"khz_per_utterance": (N / ms) if ok else 0.0, "samples_per_sec": (sh.B * N / ms * 1e3) if ok else 0.0,
-            "kernel": info, "samples": N, "chunk": chunk, "batch": sh.B}
+            "kernel": info, "samples": N, "chunk": chunk, "batch": sh.B, "shader_clock_ghz": round(ghz, 3)}
 
 
 def end_to_end_khz(w, B, chunk=256, chunks=4, seed=21):
@@ -632,10 +636,37 @@ def main():
                 big = Shape(sh.name, sh.R, sh.S, sh.A, sh.L, sh.maxD, 16 * chains)
                 r = reference_definition_khz(big, 3, N=4096, chunk=2048)
                 refdef[sh.name]["multi_cu_chain_full_gpu"] = r
-                refdef[sh.name]["max_realtime_batch_multi_cu"] = big.B if r["khz_per_utterance"] >= REALTIME_KHZ and "wavenet_chain" in r["kernel"] else None
+                best_mc = big.B if r["khz_per_utterance"] >= REALTIME_KHZ and "wavenet_chain" in r["kernel"] else None
+                if sh is C4:
+                    # round 5: batches beyond the resident chains ride the same chains, several tiles per chain (the stages work
+                    # through them in turn; nv_wavenet_persistent.cuh:110 loops its blocks over the whole batch): the largest that
+                    # stays real time, found at steady state (samples 640.., conditioning packed block by block) and then measured by
+                    # the reference's definition
+                    sweep_mc = {}
+                    for tpc in (6, 5, 4, 3, 2):
+                        if extras_left() < 40:
+                            skipped.append("reference_definition.%s.tiles_per_chain_%d" % (sh.name, tpc))
+                            continue
+                        note("reference_definition %s, %d tiles per chain" % (sh.name, tpc))
+                        shb = Shape(sh.name, sh.R, sh.S, sh.A, sh.L, sh.maxD, 16 * chains * tpc)
+                        k, info_k = measure_steady_khz(make_weights(shb, seed=1), shb.B, 1024, sh=shb, impl=3)
+                        sweep_mc[str(shb.B)] = k
+                        if k >= REALTIME_KHZ and "wavenet_chain" in info_k:
+                            n_rd = 4096
+                            while n_rd > 512 and n_rd * shb.L * shb.B * 2 * shb.R * 4 > 40e9:      # (the harness hands over the whole fp32 tensor)
+                                n_rd //= 2
+                            r = reference_definition_khz(shb, 3, N=n_rd, chunk=n_rd // 2)
+                            r["steady_state_khz_per_utterance"] = k
+                            r["mfma_frac_of_dense_fp16_peak"] = shb.flops * shb.B * k * 1e3 / (MFMA_F16_PEAK_TFLOPS * 1e12)
+                            r["tiles_per_chain"] = tpc
+                            refdef[sh.name]["multi_cu_chain_tiles_per_chain"] = r
+                            if r["khz_per_utterance"] >= REALTIME_KHZ:
+                                best_mc = shb.B
+                            break
+                    refdef[sh.name]["tiles_per_chain_sweep_steady_khz"] = sweep_mc
+                refdef[sh.name]["max_realtime_batch_multi_cu"] = best_mc
         bt = 64 * ncu                                 # four tiles per CU: not real time
-        # between three and four tiles per CU the engine runs one round of wn::wavenet_bcast workgroups (every wave its own tile,
-        # weights broadcast through LDS); beyond that, whole rounds of three-tile wavenet_wg workgroups: throughput, not real
+        # beyond three tiles per CU a launch has more three-tile wavenet_wg workgroups than CUs (whole rounds): throughput, not real
         # time; reported at four and at six tiles per CU (= two full rounds)
         thr = {"definition": "batches beyond the real-time capacity: more utterances per GPU at a lower rate per utterance "
                              "(steady state, samples 640..1151; the engine's own choice of organisation)", "points": []}

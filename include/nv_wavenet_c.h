@@ -54,9 +54,8 @@ nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int m
  * constructor; 0 = from `implementation` and the batch size like nvw_create):
  *   1 wavenet_wg (1, 2 or 3 tiles of 16 utterances per workgroup by batch size)   2 / 3 / 4 wavenet_wg with exactly 1 / 2 / 3
  *   (three: fp16, R <= 64; two tiles otherwise)   5 wavenet_chain (multi-CU, resident weights, fewest CUs)
- *   6 wavenet_chain with one layer per CU   7 (= 8) wavenet_bcast (every wave runs the whole network for its own tile, the
- *   weights broadcast to the four waves of a workgroup through an LDS ring; R = 64 shapes, others run wavenet_wg)
- *   9 retired (was wavenet_bcast with two tiles per wave): refused like any number out of range.
+ *   6 wavenet_chain with one layer per CU   7, 8, 9 retired (were wavenet_bcast -- every wave the whole network for its own
+ *   tile, weights broadcast through an LDS ring -- and its variants; removed in round 5): refused like any number out of range.
  * Returns NULL when the shape does not fit a CU in that organisation (the reference's variants print
  * and return false for shapes they do not support, nv_wavenet_singleblock.cuh:273-286). */
 nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, int max_dilation,

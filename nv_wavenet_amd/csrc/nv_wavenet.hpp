@@ -35,7 +35,6 @@
 #include <type_traits>
 #include <vector>
 
-#include "wn_bcast.hpp"
 #include "wn_chain.hpp"
 #include "wn_kernels.hpp"
 
@@ -58,11 +57,10 @@ enum nvwOrganisation {
     NVW_ORG_WG3 = 4,      // wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64; else two)
     NVW_ORG_CHAIN = 5,    // wn::wavenet_chain, as many layers per CU as stay resident
     NVW_ORG_CHAIN1 = 6,   // wn::wavenet_chain, one layer per CU
-    NVW_ORG_BCAST = 7,    // wn::wavenet_bcast: every wave runs the whole network for its own tile (4 per workgroup), weights
-                          // broadcast through an LDS ring (R = 64 shapes; others run wavenet_wg)
-    NVW_ORG_BCAST1 = 8,   // (the same: kept from the time a two-tiles-per-wave variant existed)
-    NVW_ORG_RETIRED9 = 9, // was: two tiles per wave (measured no faster than two rounds of one tile per wave; removed) -- refused
-    NVW_ORG_LAST = NVW_ORG_BCAST1
+    NVW_ORG_RETIRED7 = 7, // were: wn::wavenet_bcast (every wave its own tile, weights broadcast through an LDS ring; rounds 3-4) and its
+    NVW_ORG_RETIRED8 = 8, // variants: measured, never real time anywhere, removed in round 5 (LABNOTES.md) -- refused
+    NVW_ORG_RETIRED9 = 9,
+    NVW_ORG_LAST = NVW_ORG_CHAIN1
 };
 
 template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
@@ -256,7 +254,10 @@ protected:
         const int ns = (L + CC::LPC - 1) / CC::LPC;
         return (L + ns - 1) / ns;
     }
-    bool chainFits(int lpc, int tiles) const { return lpc > 0 && chainStagesFor(m_numLayers, lpc) * tiles <= m_numCUs; }
+    // a chain of `stages` CUs serves up to TPC_MAX tiles in turn (round 5): all tiles of the batch ride resident chains
+    bool chainFits(int lpc, int tiles) const {
+        return lpc > 0 && chainStagesFor(m_numLayers, lpc) * ((tiles + CC::TPC_MAX - 1) / CC::TPC_MAX) <= m_numCUs;
+    }
     // The single-workgroup organisation: one, two or -- fp16, R <= 64 -- three tiles per workgroup (split over the 4 SIMDs
     // of a CU) by batch size, see wgTiles(); beyond three tiles per CU the launch simply has more workgroups than CUs.
     int singleOrg(int) const { return NVW_ORG_WG; }
@@ -271,25 +272,27 @@ protected:
         static constexpr double kHeadUs = 4.0;               // head GEMMs + softmax + embedding, either organisation
         static constexpr double kChainHopUs = 1.1;           // one stage hand-off (hop 0.55 + entry / exit)
         static constexpr double kChainLayerUs(int r) { return r >= 128 ? 0.55 : 0.4; }   // resident-weight layer of a stage
-        // one round of workgroups on every CU, C3 fp16, steady state (profiles/r04_*): three-tile wavenet_wg 36.5 us per
-        // sample, wavenet_bcast (four tiles per workgroup) 54 us: bcast wins exactly where wavenet_wg needs a second round and
-        // bcast does not
-        static constexpr double kWg3RoundUs = 36.5, kBcastRoundUs = 54.0;
+        // several tiles per chain: a sample of a tile occupies the busiest stage (the head) this long, so a chain's sample period is
+        // max(trip round the chain, tiles per chain x this)  (round 5, C4: profiles/r05_chain_c4_tiles_per_chain.json)
+        static constexpr double kChainUnitUs = 5.0;
     };
     int pickOrganisation(int tiles) const {
-        if constexpr (F16 && BC1) {
-            const int cus = m_numCUs;
-            const double tWg = OrgTimes::kWg3RoundUs * ((tiles + 3 * cus - 1) / (3 * cus));
-            const double tBc = OrgTimes::kBcastRoundUs * ((tiles + 4 * cus - 1) / (4 * cus));
-            if (tiles > 3 * cus && tBc < 0.9 * tWg && bcastFits()) return NVW_ORG_BCAST;      // (a near tie stays with wavenet_wg)
-        }
         const int single = singleOrg(tiles);
         const int lpc = chainLpcMax(m_numLayers);
         if (!chainFits(lpc, tiles)) return single;
         const double wBytes = sizeof(elem) * ((double)m_numLayers * (5.0 * R * R + (double)S * R) + (double)A * S + (double)A * A);
-        const double tStream = wBytes / (OrgTimes::kStreamBytesPerClk * OrgTimes::kClockMHz) + OrgTimes::kStreamLayerUs * m_numLayers + OrgTimes::kHeadUs;
-        const double tChain = OrgTimes::kChainHopUs * chainStagesFor(m_numLayers, lpc) + OrgTimes::kChainLayerUs(R) * m_numLayers + OrgTimes::kHeadUs;
-        return tChain < tStream ? NVW_ORG_CHAIN : single;
+        // one workgroup per (1 .. wgMax) tiles, whole rounds of them beyond one per CU
+        const int wgMax = WG3 ? 3 : WG2 ? 2 : 1;
+        const int rounds = (tiles + wgMax * m_numCUs - 1) / (wgMax * m_numCUs);
+        const double tStream = (wBytes / (OrgTimes::kStreamBytesPerClk * OrgTimes::kClockMHz) + OrgTimes::kStreamLayerUs * m_numLayers + OrgTimes::kHeadUs) * rounds;
+        const int stages = chainStagesFor(m_numLayers, lpc), perLaunch = m_numCUs / stages;
+        const int tpc = (tiles + perLaunch - 1) / perLaunch;
+        double tChain = OrgTimes::kChainHopUs * stages + OrgTimes::kChainLayerUs(R) * m_numLayers + OrgTimes::kHeadUs;
+        if (tpc * OrgTimes::kChainUnitUs > tChain) tChain = tpc * OrgTimes::kChainUnitUs;
+        // (the time model of wavenet_wg is its one-tile latency: with two or three tiles per workgroup, i.e. beyond one tile per CU, a
+        //  sample takes up to twice as long -- the chain is only preferred there when even that is slower)
+        const double tWg = tiles > m_numCUs ? tStream * (tiles > 2 * m_numCUs && WG3 ? 1.9 : WG2 ? 1.4 : 1.0) : tStream;
+        return tChain < tWg ? NVW_ORG_CHAIN : single;
     }
     void resolveOrganisation(int requested) {
         const int tiles = (m_maxBatch + 15) / 16;
@@ -308,23 +311,24 @@ protected:
         }
         if (org == NVW_ORG_CHAIN && !chainFits(chainLpcMax(m_numLayers), tiles)) org = singleOrg(tiles);
         if (org == NVW_ORG_CHAIN1 && !(CC::SUPPORTED && chainFits(1, tiles))) org = singleOrg(tiles);
-        if (org >= NVW_ORG_BCAST && org <= NVW_ORG_BCAST1 && !bcastFits()) org = singleOrg(tiles);
         m_org = org;
         m_chainLpc = org == NVW_ORG_CHAIN ? chainLpcMax(m_numLayers) : org == NVW_ORG_CHAIN1 ? 1 : 0;
         m_chainStages = m_chainLpc ? chainStagesFor(m_numLayers, m_chainLpc) : 0;
     }
     bool isChain() const { return m_chainLpc > 0; }
-    // ---- wn::wavenet_bcast ------------------------------------------------------------------------------------------
-    static constexpr bool BC1 = wn::BCfg<F16, R, S, A, 1>::SUPPORTED;
-    bool isBcast() const { return m_org >= NVW_ORG_BCAST && m_org <= NVW_ORG_BCAST1; }
-    template <int BTW> static size_t bcastLds(int L, bool dump, int emb) { return wn::BCfg<F16, R, S, A, BTW>::ldsBytes(L, dump, emb); }
-    // the shape has the kernel, the model is deep enough for its two-layer lookahead and its tables fit the LDS beside the ring
-    bool bcastFits() const {
-        if constexpr (BC1) return m_numLayers >= 3 && bcastLds<1>(m_numLayers, true, 0) <= kLdsMax;
-        return false;
+    // tiles per chain for a batch of `tiles` tiles: as few as put every tile on a resident chain, at most TPC_MAX
+    int chainTpc(int tiles) const {
+        const int perLaunch = m_numCUs / (m_chainStages > 0 ? m_chainStages : 1);
+        int tpc = perLaunch > 0 ? (tiles + perLaunch - 1) / perLaunch : 1;
+#ifdef WN_CHAIN_TPC_MIN      // (experiment: the mailbox layout of several tiles per chain for launches that have one)
+        if (tpc < WN_CHAIN_TPC_MIN) tpc = WN_CHAIN_TPC_MIN;
+#endif
+        return tpc < 1 ? 1 : tpc > CC::TPC_MAX ? CC::TPC_MAX : tpc;
     }
     // tiles per workgroup of wn::wavenet_wg for a batch of `tiles` tiles
     static constexpr bool WG3 = F16 && R <= 64;   // shapes with a three-tile instantiation
+    static constexpr bool WG2 = R < 128;          // ... with a two-tile one (two tiles of R >= 128 need the registers of three: 300-560 spilled,
+                                                  // slower than one tile; they fit the LDS only for shallow models anyway)
     bool wg3Fits() const {
         if constexpr (WG3) return ldsFits<3>();
         return false;
@@ -333,7 +337,8 @@ protected:
         const bool three = m_org == NVW_ORG_WG3 || (m_org == NVW_ORG_WG && tiles > 2 * m_numCUs);
         if (three && wg3Fits()) return 3;
         const bool two = three || m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs);
-        return (two && ldsFits<2>()) ? 2 : 1;
+        if constexpr (WG2) return (two && ldsFits<2>()) ? 2 : 1;
+        return 1;
     }
 
 public:
@@ -369,7 +374,7 @@ public:
         // exactly the tiles of the batch
         {
             const int tiles = (batchSize + 15) / 16;
-            const int group = isChain() ? 1 : isBcast() ? 4 : wgTiles(tiles);
+            const int group = isChain() ? 1 : wgTiles(tiles);
             m_tiles = (tiles + group - 1) / group * group;
         }
 
@@ -423,7 +428,10 @@ public:
         gpuErrChk(hipMalloc(&m_chainStatus, 4 * sizeof(unsigned)));
         gpuErrChk(hipMemset(m_chainStatus, 0, 4 * sizeof(unsigned)));
         if (isChain()) {
-            m_mailBytes = CC::mailGranules((batchSize + 15) / 16, m_chainStages) * sizeof(unsigned long long);
+            {
+                const int tiles = (batchSize + 15) / 16, perLaunch = m_numCUs / m_chainStages;
+                m_mailBytes = CC::mailGranules(tiles < perLaunch ? tiles : perLaunch, m_chainStages, chainTpc(tiles)) * sizeof(unsigned long long);
+            }
             gpuErrChk(hipMalloc(&m_mail, m_mailBytes));
             gpuErrChk(hipMemset(m_mail, 0, m_mailBytes));
             gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_chain<F16, R, S, A, true>,
@@ -440,13 +448,10 @@ public:
         hipLaunchKernelGGL(wn::silence_kernel, dim3(1), dim3(256), 0, 0, m_yInPrev, m_yInCur, m_maxBatch);
         gpuErrChk(hipGetLastError());
 
-        if (isBcast()) {
-            if constexpr (BC1) allowBcast<1>();
-        }
         if (ldsFits<1>()) {            // (a chain engine launches wavenet_wg as its fallback)
             allowLds<1>();
             if (!isChain()) {
-                allowLds<2>();
+                if constexpr (WG2) allowLds<2>();
                 if constexpr (WG3) allowLds<3>();
             }
         }
@@ -792,22 +797,21 @@ public:
         const int tiles = (batch_size + 15) / 16;
         const bool dump = F16 ? dumpActivations : true;
         if (isChain() && !m_featPtr) {
-            snprintf(buf, n, "wn::wavenet_chain<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d wgs=%d lds=%zu",
-                     F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, tiles, m_chainStages * tiles,
-                     CC::ldsBytes());
-            return;
-        }
-        if (isBcast() && !m_condRaw && !m_featPtr) {
-            const int btw = 1;
-            const int emb = bcastEmb(dump);
-            snprintf(buf, n, "wn::wavenet_bcast<%s,%d,%d,%d,BTW=%d,EMBLDS=%d,DUMP=%d> tiles/wave=%d wgs=%d lds=%zu", F16 ? "fp16" : "fp32", R, S,
-                     A, btw, emb, dump ? 1 : 0, btw, (tiles + 4 * btw - 1) / (4 * btw),
-                     bcastLdsAny<1>(dump, emb));
+            const int perLaunch = m_numCUs / m_chainStages, chains = tiles < perLaunch ? tiles : perLaunch;
+            snprintf(buf, n, "wn::wavenet_chain<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d tiles/chain=%d wgs=%d lds=%zu",
+                     F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, chains, chainTpc((m_maxBatch + 15) / 16),
+                     m_chainStages * chains, CC::ldsBytes());
             return;
         }
         const int bt = wgTiles(tiles);
-        int nEmb = bt == 2 ? embTables<2>() : embTables<1>();
-        size_t lds = bt == 2 ? ldsNeed<2>(m_numLayers, nEmb) : ldsNeed<1>(m_numLayers, nEmb);
+        int nEmb = embTables<1>();
+        size_t lds = ldsNeed<1>(m_numLayers, nEmb);
+        if constexpr (WG2) {
+            if (bt == 2) {
+                nEmb = embTables<2>();
+                lds = ldsNeed<2>(m_numLayers, nEmb);
+            }
+        }
         if constexpr (WG3) {
             if (bt == 3) {
                 nEmb = embTables<3>();
@@ -979,9 +983,8 @@ public:
         if (p.count <= 0) return true;
 
         const int tiles = (batch_size + 15) / 16;
-        // (computing the conditioning from the features is wavenet_wg's: chain / bcast engines run it for such a launch)
-        bool result = m_featPtr ? launchWg(p, tiles, stream)
-                      : isChain() ? launchChain(p, tiles, stream) : (isBcast() && !m_condRaw) ? launchBcast(p, tiles, stream) : launchWg(p, tiles, stream);
+        // (computing the conditioning from the features is wavenet_wg's: a chain engine runs it for such a launch)
+        bool result = (isChain() && !m_featPtr) ? launchChain(p, tiles, stream) : launchWg(p, tiles, stream);
         if (m_pcmUser != NULL) {
             // the indices of a finished sample are final: the expansion is a per-element map of yOut
             hipLaunchKernelGGL(wn::mulaw_pcm_kernel, dim3(gridFor((size_t)batch_size * p.count)), dim3(256), 0, stream,
@@ -1064,46 +1067,6 @@ protected:
         gpuErrChk(hipMemcpy(&s, m_chainStatus + i, sizeof(unsigned), hipMemcpyDeviceToHost));
         return s;
     }
-    // wavenet_bcast: the current tap's embedding table in LDS when there is room
-    template <int BTW> size_t bcastLdsAny(bool dump, int emb) const {
-        if constexpr (BC1) return bcastLds<BTW>(m_numLayers, dump, emb);
-        return 0;
-    }
-    int bcastEmb(bool dump) const { return bcastLdsAny<1>(dump, 1) <= kLdsMax ? 1 : 0; }
-    template <int BTW, bool EMB, bool DUMP> void allowBcastK() {
-        const size_t need = bcastLds<BTW>(m_numLayers, DUMP, EMB ? 1 : 0);
-        if (need <= kLdsMax)
-            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_bcast<F16, R, S, A, BTW, EMB, DUMP>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-    }
-    template <int BTW> void allowBcast() {
-        allowBcastK<BTW, false, true>();
-        allowBcastK<BTW, true, true>();
-        if constexpr (F16) {
-            allowBcastK<BTW, false, false>();
-            allowBcastK<BTW, true, false>();
-        }
-    }
-    template <int BTW, bool EMB, bool DUMP> bool launchBcastK(wn::Params& p, int tiles, hipStream_t stream) {
-        using BB = wn::BCfg<F16, R, S, A, BTW>;
-        const int grid = (tiles + BB::TILES_WG - 1) / BB::TILES_WG;
-        hipLaunchKernelGGL((wn::wavenet_bcast<F16, R, S, A, BTW, EMB, DUMP>), dim3(grid), dim3(BB::THREADS),
-                           bcastLds<BTW>(m_numLayers, DUMP, EMB ? 1 : 0), stream, p);
-        return hipGetLastError() == hipSuccess;
-    }
-    template <int BTW> bool launchBcastB(wn::Params& p, int tiles, hipStream_t stream) {
-        bool dump = true;
-        if constexpr (F16) dump = p.dump != 0;
-        const bool emb = bcastEmb(dump) != 0;
-        if constexpr (F16) {
-            if (!dump) return emb ? launchBcastK<BTW, true, false>(p, tiles, stream) : launchBcastK<BTW, false, false>(p, tiles, stream);
-        }
-        return emb ? launchBcastK<BTW, true, true>(p, tiles, stream) : launchBcastK<BTW, false, true>(p, tiles, stream);
-    }
-    bool launchBcast(wn::Params& p, int tiles, hipStream_t stream) {
-        if constexpr (BC1) return launchBcastB<1>(p, tiles, stream);
-        return false;
-    }
     // wavenet_wg by batch size: one, two or three tiles per workgroup
     bool launchWg(wn::Params& p, int tiles, hipStream_t stream) {
         const int bt = wgTiles(tiles);
@@ -1111,7 +1074,11 @@ protected:
             if constexpr (WG3) return launch<3>(p, tiles, stream);
             return false;
         }
-        return bt == 2 ? launch<2>(p, tiles, stream) : launch<1>(p, tiles, stream);
+        if (bt == 2) {
+            if constexpr (WG2) return launch<2>(p, tiles, stream);
+            return false;
+        }
+        return launch<1>(p, tiles, stream);
     }
     // a chain launch that gives up can be re-run by wavenet_wg when the model's bias table fits one workgroup's LDS
     bool chainHasFallback() const { return ldsFits<1>(); }
@@ -1137,17 +1104,24 @@ protected:
         if constexpr (F16) dump = p.dump != 0;
         const bool fallback = m_ringShadow != NULL;
         const size_t ringTileElems = (size_t)m_ringSlots * R * 16;
-        for (int t0 = 0; t0 < tiles; t0 += perLaunch) {
+        // tiles beyond the chains that are resident at once ride the same chains, up to TPC_MAX per chain (round 5); more than
+        // that takes further launches
+        const int tpc = chainTpc((m_maxBatch + 15) / 16);        // (what the mailboxes were sized for)
+        cp.tpc = tpc;
+        const int tilesPerLaunch = perLaunch * tpc;
+        for (int t0 = 0; t0 < tiles; t0 += tilesPerLaunch) {
+            const int nT = tiles - t0 < tilesPerLaunch ? tiles - t0 : tilesPerLaunch;
             cp.tile0 = t0;
-            cp.chains = tiles - t0 < perLaunch ? tiles - t0 : perLaunch;
-            const int b0 = t0 * 16, nb = (p.batch - b0 < cp.chains * 16 ? p.batch - b0 : cp.chains * 16);
+            cp.ntiles = nT;
+            cp.chains = nT < perLaunch ? nT : perLaunch;
+            const int b0 = t0 * 16, nb = (p.batch - b0 < nT * 16 ? p.batch - b0 : nT * 16);
             if (fallback) {
                 gpuErrChk(hipMemcpyAsync(m_ringShadow + t0 * ringTileElems, m_ring + t0 * ringTileElems,
-                                         cp.chains * ringTileElems * sizeof(elem), hipMemcpyDeviceToDevice, stream));
+                                         nT * ringTileElems * sizeof(elem), hipMemcpyDeviceToDevice, stream));
                 gpuErrChk(hipMemcpyAsync(m_histShadow + b0, m_yInPrev + b0, nb * sizeof(int), hipMemcpyDeviceToDevice, stream));
                 gpuErrChk(hipMemcpyAsync(m_histShadow + m_maxBatch + b0, m_yInCur + b0, nb * sizeof(int), hipMemcpyDeviceToDevice, stream));
             }
-            gpuErrChk(hipMemsetAsync(m_mail, 0, CC::mailGranules(cp.chains, m_chainStages) * sizeof(unsigned long long), stream));
+            gpuErrChk(hipMemsetAsync(m_mail, 0, CC::mailGranules(cp.chains, m_chainStages, tpc) * sizeof(unsigned long long), stream));
             const int grid = 8 * m_chainStages * ((cp.chains + 7) / 8);
             p.embLds = CC::embTables();
             p.gate = NULL;
@@ -1159,7 +1133,7 @@ protected:
             }
             if (hipGetLastError() != hipSuccess) return false;
             if (fallback) {
-                const size_t n16 = cp.chains * ringTileElems * sizeof(elem) / 16;
+                const size_t n16 = nT * ringTileElems * sizeof(elem) / 16;
                 hipLaunchKernelGGL(wn::chain_restore_kernel, dim3(gridFor(n16)), dim3(256), 0, stream, (const unsigned*)m_chainStatus,
                                    (wn::uintx4*)(m_ring + t0 * ringTileElems), (const wn::uintx4*)(m_ringShadow + t0 * ringTileElems), n16,
                                    m_yInPrev + b0, m_yInCur + b0, (const int*)(m_histShadow + b0), (const int*)(m_histShadow + m_maxBatch + b0), nb);
@@ -1171,8 +1145,8 @@ protected:
                 const int nEmb = embTables<1>();
                 q.embLds = nEmb;
                 bool ok;
-                if (nEmb) ok = launchGated<true>(q, t0, cp.chains, nEmb, stream);
-                else ok = launchGated<false>(q, t0, cp.chains, 0, stream);
+                if (nEmb) ok = launchGated<true>(q, t0, nT, nEmb, stream);
+                else ok = launchGated<false>(q, t0, nT, 0, stream);
                 if (!ok) return false;
                 hipLaunchKernelGGL(wn::chain_settle_kernel, dim3(1), dim3(1), 0, stream, m_chainStatus);
                 if (hipGetLastError() != hipSuccess) return false;

@@ -54,8 +54,10 @@ struct ChainParams {
     unsigned* status;           // [0]: 0 = fine, else the code of the first time-out (host checks after the launch)
     int stages;                 // layer stages + 1 (head)
     int lpc;                    // layers per layer stage (<= CCfg::LPC)
-    int chains;                 // utterance tiles of this launch
-    int tile0;                  // first tile (chains of one launch cover tiles tile0 .. tile0+chains-1)
+    int chains;                 // chains of this launch
+    int tile0;                  // first tile of this launch
+    int ntiles;                 // tiles of this launch (<= chains * tpc): chain c serves tiles tile0 + q * chains + c, q = 0 .. tpc-1
+    int tpc;                    // tiles per chain (round 5): every stage works through its chain's tiles in turn, sample by sample
     long long timeoutTicks;     // bound of every spin, in ticks of the 100 MHz wall clock
 };
 
@@ -138,7 +140,10 @@ struct CCfg {
     static constexpr int OFF_HLG = C::ALIAS_LG ? OFF_HZS : OFF_HZS + C::ZSBUF;
     static constexpr int OFF_HY = C::ALIAS_LG ? OFF_HZS + (C::ZSBUF > C::LGBUF ? C::ZSBUF : C::LGBUF) : OFF_HLG + C::LGBUF;
     static constexpr int OFF_HB = OFF_HY + C::YBUF;
-    static constexpr int OFF_HE = (OFF_HB + (S + 2 * A) * 4 + 15) & ~15;
+    // tiles a chain may keep in flight (the head keeps their sample history in LDS: [TPC_MAX][older | current][16 utterances])
+    static constexpr int TPC_MAX = 8;
+    static constexpr int OFF_HH = (OFF_HB + (S + 2 * A) * 4 + 15) & ~15;
+    static constexpr int OFF_HE = OFF_HH + TPC_MAX * 2 * 16 * 4;
     static size_t headLds(int embTables) { return (size_t)OFF_HE + (size_t)embTables * A * R * sizeof(typename C::P::elem); }
     static int embTables() { return headLds(2) <= (size_t)LDS_MAX ? 2 : headLds(1) <= (size_t)LDS_MAX ? 1 : 0; }
     static size_t ldsBytes() {
@@ -148,18 +153,18 @@ struct CCfg {
     // mailboxes of one stage, in granules
     static constexpr int XG = R * 16, SG = S * 16;
     static constexpr size_t placeWords(int chains, int stages) { return ((size_t)chains * stages + 63) & ~(size_t)63; }
-    static constexpr size_t mailGranules(int chains, int stages) { return placeWords(chains, stages) + (size_t)chains * stages * (XG + SG); }
+    static constexpr size_t mailGranules(int chains, int stages, int tpc = 1) { return placeWords(chains, stages) + (size_t)chains * stages * tpc * (XG + SG); }
 };
 
 // Experiment build (-DWN_CHAIN_TIMING): wave 0 of every stage stamps the 100 MHz wall clock (one counter for
 // the whole chip) at its phase boundaries for samples 8..15 of the launch into p.p, read as
-// unsigned long long [stage][8 samples][16 events] (scripts/chain_phase.py).
+// unsigned long long [stage][tile of the chain q][8 samples][16 events] (chain 0 only; scripts/chain_phase.py).
 #ifdef WN_CHAIN_TIMING
 #define WN_CT_DECL unsigned long long cts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define WN_CT(ev) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); cts[ev] = __builtin_amdgcn_s_memrealtime(); }
 #define WN_CT_FLUSH(stageIdx, tt)                                                                           \
-    if (w == 0 && lane == 0 && (tt) >= 8 && (tt) < 16) {                                                      \
-        unsigned long long* dbg = (unsigned long long*)p.p + ((size_t)(stageIdx) * 8 + ((tt) - 8)) * 16;      \
+    if (w == 0 && lane == 0 && chainIdx == 0 && (tt) >= 8 && (tt) < 16) {                                     \
+        unsigned long long* dbg = (unsigned long long*)p.p + (((size_t)(stageIdx) * nq + q) * 8 + ((tt) - 8)) * 16; \
         _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) dbg[q_] = cts[q_];                                 \
     }
 #else
@@ -345,7 +350,7 @@ WN_DEV void gemm_w(const floatx4 (&wag)[CC::NAG ? CC::NAG : 1], const typename P
 // layer stage: layers l0 .. l0+nl-1 of tile `tile`
 // ------------------------------------------------------------------------------------------------
 template <bool F16, int R, int S, int A, bool DUMP>
-WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int tile, int chainIdx, int stage) {
+WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int chainIdx, int stage) {
     using CC = CCfg<F16, R, S, A>;
     using C = typename CC::C;
     using P = Prec<F16>;
@@ -369,17 +374,12 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
     const unsigned laneOff = (unsigned)lane * 16u;
     char* const wlds = lds + CC::OFF_LW + (size_t)w * LP * NLD * 1024;     // this wave's slice
 
-    const int b = tile * 16 + j;
-    const bool uvalid = b < p.batch;
-    const int ub = uvalid ? b : p.batch - 1;
-
-    // mailboxes: this stage's inputs, the next stage's inputs
+    // Several tiles per chain (round 5): the stage works through its chain's tiles q = 0 .. nq-1 in turn, sample by sample -- tile
+    // q's sample t+1 cannot arrive before the head has finished its sample t, a whole trip round the chain later, and the stage
+    // serves the other tiles meanwhile.  Every tile has its own single-slot mailboxes; the weights are resident once.
+    const int nq = (cp.ntiles - chainIdx + cp.chains - 1) / cp.chains;
     unsigned long long* const boxes = cp.mail + CC::placeWords(cp.chains, cp.stages);
-    unsigned long long* const mbase = boxes + ((size_t)chainIdx * cp.stages + stage) * (CC::XG + CC::SG);
-    const unsigned long long* const xin = mbase;
-    const unsigned long long* const skin = mbase + CC::XG;
-    unsigned long long* const xout = mbase + (CC::XG + CC::SG);
-    unsigned long long* const skout = xout + CC::XG;
+    unsigned long long* const mstage = boxes + ((size_t)chainIdx * cp.stages + stage) * cp.tpc * (CC::XG + CC::SG);
     gu32* const status = (gu32*)cp.status;
     bool sameXcd = false;
     if (!chain_place(cp.mail, chainIdx * cp.stages + stage, chainIdx * cp.stages + stage + 1, status, sameXcd, cp.timeoutTicks)) return;
@@ -426,9 +426,7 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
         }
     }
     const size_t condStride = (size_t)p.tiles * NW * C::COND_FR * 1024;             // one (sample, layer) row
-    const char* const condMine = (const char*)p.cond + ((size_t)tile * NW + w) * C::COND_FR * 1024;
     const size_t ringTile = (size_t)p.ringSlots * KF_R * 1024;
-    char* const ringMine = (char*)p.ring + (size_t)tile * ringTile;
 
     frag selA[P::TPF];
 #pragma unroll
@@ -437,10 +435,23 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
         for (int e = 0; e < P::EPL; e++) selA[tt][e] = (elem)(((e >> 2) == tt && g * 4 + (e & 3) == j) ? 1.0f : 0.0f);
 
     const int tEnd = p.initSample + p.count;
-    for (int t = p.initSample; t < tEnd; t++) {
+    for (int t = p.initSample; t < tEnd; t++)
+    for (int q = 0; q < nq; q++) {
         const unsigned tag = (unsigned)(t - p.initSample) + 1u;
         const bool dumpNow = DUMP && p.dump && (t == tEnd - 1);
-        // every ring store of the previous sample has completed (and is visible to the whole workgroup:
+        // this unit's tile: utterances, mailboxes (own inputs; the next stage's inputs), conditioning, ring
+        const int tile = cp.tile0 + q * cp.chains + chainIdx;
+        const int b = tile * 16 + j;
+        const bool uvalid = b < p.batch;
+        const int ub = uvalid ? b : p.batch - 1;
+        unsigned long long* const mbase = mstage + (size_t)q * (CC::XG + CC::SG);
+        const unsigned long long* const xin = mbase;
+        const unsigned long long* const skin = mbase + CC::XG;
+        unsigned long long* const xout = mbase + (size_t)cp.tpc * (CC::XG + CC::SG);
+        unsigned long long* const skout = xout + CC::XG;
+        const char* const condMine = (const char*)p.cond + ((size_t)tile * NW + w) * C::COND_FR * 1024;
+        char* const ringMine = (char*)p.ring + (size_t)tile * ringTile;
+        // every ring store of the previous unit has completed (and is visible to the whole workgroup:
         // one L1 per CU); also orders the reuse of the h images and of the bias table after the prologue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wg_barrier();
@@ -520,6 +531,7 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
 
         // ---- the sample arrives: x_l0[t], this wave's tiles (fp32) ----------------------------------
         floatx4 x[HTW];
+        frag xring[LP][C::XPW];
         WN_CT(1)
         if (!recv_tiles_fast<HTW, NW>(xin, w, lane, tag, x, status, 0x100u + (unsigned)stage, cp.timeoutTicks)) return;
         unsigned long long skq[STW * 4];
@@ -538,15 +550,12 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
                 frag xb[KF_R];
                 lds_get_frags<F16, KF_R>(xbuf, lane, xb);
                 if (li == 0) WN_CT(8)
-                // x_l[t] replaces x_l[t-d] in the ring (each wave stores its share of the fragments)
-                {
-                    const int d = dl[li].d;
-                    char* rp = ringMine + (size_t)(unsigned)(dl[li].off + (t & (d - 1))) * (KF_R * 1024);
+                // x_l[t] will replace x_l[t-d] in the ring (each wave stores its share of the fragments): kept here, stored behind
+                // the x hand-off (round 5: nothing that can wait is queued in front of the stores of the hand-off)
 #pragma unroll
-                    for (int i = 0; i < C::XPW; i++) {
-                        const int k = w + NW * i;          // wave-uniform: no select over the xb registers
-                        if (k < KF_R) *(frag*)(rp + (size_t)k * 1024 + laneOff) = *(const frag*)(xbuf + (size_t)k * 1024 + laneOff);
-                    }
+                for (int i = 0; i < C::XPW; i++) {
+                    const int k = w + NW * i;              // wave-uniform: no select over the xb registers
+                    if (k < KF_R) xring[li][i] = *(const frag*)(xbuf + (size_t)k * 1024 + laneOff);
                 }
                 gemm_w<F16, CC, 0, 0, 2 * HTW, KF_R>(wag[li], wvg[li], wl, laneOff, acc[li], xb);
                 if (li == 0) {
@@ -566,9 +575,11 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
                 frag hb[KF_R];
                 lds_get_frags<F16, KF_R>(hb_img, lane, hb);
                 if (li == 0) WN_CT(12)
-                // the skip sums of the stage before are usually on their way by now: the first sweep pass for them
-                // is issued here, behind the last own layer's residual GEMM, instead of after the x hand-off
-                if (li + 1 == nl && stage != 0) sweep_issue<STW, NW>(skin, w, lane, skq);
+                // the skip sums of the stage before are usually on their way by now; their first sweep pass is issued right
+                // behind the x hand-off
+                // (round 5: NOT before the x hand-off any more -- vector-memory instructions issue in order, and the sixteen L1-bypassing
+                //  loads of this sweep in front of the x stores cost every stage 0.2 us of its arrival-to-departure path: 25.6 -> 26.8 kHz
+                //  at C4, and 23.6 -> 26.3 with four tiles per chain, where the mailboxes no longer sit in a quiet L2)
                 floatx4 xa[HTW];
 #pragma unroll
                 for (int i = 0; i < HTW; i++) xa[i] = *(const floatx4*)(bl + 2 * R + (w + NW * i) * 16 + g * 4) + x[i];
@@ -596,6 +607,19 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
         }
         WN_CT(3)
         if (!lastLayerStage) send_tiles<HTW, NW>(xout, w, lane, tag, x, sameXcd);   // (the last layer's output is unused)
+        if (stage != 0) sweep_issue<STW, NW>(skin, w, lane, skq);
+#pragma unroll
+        for (int li = 0; li < LP; li++) {
+            if (li < nl) {
+                const int d = dl[li].d;
+                char* rp = ringMine + (size_t)(unsigned)(dl[li].off + (t & (d - 1))) * (KF_R * 1024);
+#pragma unroll
+                for (int i = 0; i < C::XPW; i++) {
+                    const int k = w + NW * i;
+                    if (k < KF_R) *(frag*)(rp + (size_t)k * 1024 + laneOff) = xring[li][i];
+                }
+            }
+        }
         WN_CT(4)
 
         // ---- behind the sample: running skip sums  skip <- Wskip_l h_l + skip  ------------------------
@@ -637,7 +661,7 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
 // head stage: final skip -> Zs -> Za -> softmax -> pick -> embedding of the next sample
 // ------------------------------------------------------------------------------------------------
 template <bool F16, int R, int S, int A, bool DUMP>
-WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int tile, int chainIdx) {
+WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int chainIdx) {
     using CC = CCfg<F16, R, S, A>;
     using C = typename CC::C;
     using P = Prec<F16>;
@@ -666,16 +690,15 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
     const int stage = cp.stages - 1;
     const unsigned laneOff = (unsigned)lane * 16u;
 
-    const int b = tile * 16 + j;
-    const bool uvalid = b < p.batch;
-    const int ub = uvalid ? b : p.batch - 1;
     const int su = tid / C::LPU, sq = tid % C::LPU;            // softmax role
 
+    const int nq = (cp.ntiles - chainIdx + cp.chains - 1) / cp.chains;      // tiles of this chain (see chain_layers)
     unsigned long long* const boxes = cp.mail + CC::placeWords(cp.chains, cp.stages);
-    unsigned long long* const mbase = boxes + ((size_t)chainIdx * cp.stages + stage) * (CC::XG + CC::SG);
-    const unsigned long long* const skin = mbase + CC::XG;
-    unsigned long long* const xout = boxes + ((size_t)chainIdx * cp.stages) * (CC::XG + CC::SG);   // stage 0
+    unsigned long long* const mstage = boxes + ((size_t)chainIdx * cp.stages + stage) * cp.tpc * (CC::XG + CC::SG);
+    unsigned long long* const mstage0 = boxes + ((size_t)chainIdx * cp.stages) * cp.tpc * (CC::XG + CC::SG);   // stage 0
     gu32* const status = (gu32*)cp.status;
+    // per-tile state of the head between two visits of a tile: the sample history
+    int* const hist = (int*)(lds + CC::OFF_HH);                                              // [TPC_MAX][older | current][16]
     bool sameXcd = false;
     if (!chain_place(cp.mail, chainIdx * cp.stages + stage, chainIdx * cp.stages, status, sameXcd, cp.timeoutTicks)) return;
 
@@ -727,16 +750,21 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
         for (int i = 0; i < PF; i++) ws.buf[i] = *(const frag*)(whead + (size_t)i * 1024 + laneOff);
     }
 
-    int yPrev = p.yInPrev[ub], yCur = p.yInCur[ub];
-    __syncthreads();   // tables and biases complete
+    if (w == 0 && g == 0) {
+        for (int q = 0; q < nq; q++) {
+            int b0 = (cp.tile0 + q * cp.chains + chainIdx) * 16 + j;
+            b0 = b0 < p.batch ? b0 : p.batch - 1;
+            hist[(q * 2 + 0) * 16 + j] = p.yInPrev[b0];
+            hist[(q * 2 + 1) * 16 + j] = p.yInCur[b0];
+        }
+    }
+    __syncthreads();   // tables, biases and history complete
 
     // embedding of the sample after (yPrev, yCur) -> stage 0 (nv_wavenet_reference.cpp:42-56)
     // ep: the older tap's row of the NEXT sample is the current tap's index of this one: gathered a whole
     // sample early (it may come from global memory when only one table fits in LDS)
     floatx4 ep[HTW];
-#pragma unroll
-    for (int i = 0; i < HTW; i++) ep[i] = rowPrev(yPrev, w + NW * i);
-    auto embed_and_send = [&](unsigned tag) {
+    auto embed_and_send = [&](int q, unsigned tag, int yCur) {
         floatx4 x0[HTW];
 #pragma unroll
         for (int i = 0; i < HTW; i++) {
@@ -748,19 +776,36 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
             }
             x0[i] = v;
         }
-        send_tiles<HTW, NW>(xout, w, lane, tag, x0, sameXcd);
+        send_tiles<HTW, NW>(mstage0 + (size_t)q * (CC::XG + CC::SG), w, lane, tag, x0, sameXcd);
     };
-    embed_and_send(1u);
+    for (int q = 0; q < nq; q++) {
+#pragma unroll
+        for (int i = 0; i < HTW; i++) ep[i] = rowPrev(hist[(q * 2 + 0) * 16 + j], w + NW * i);
+        embed_and_send(q, 1u, hist[(q * 2 + 1) * 16 + j]);
+    }
 
+    // clock probe (Params::clk, see wavenet_wg): the head of chain 0 records shader and wall clock at both ends of its sample loop
+    const bool probe = p.clk != nullptr && chainIdx == 0 && tid == 0;
+    if (probe) {
+        p.clk[0] = __builtin_amdgcn_s_memtime();
+        p.clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
     const int tEnd = p.initSample + p.count;
-    for (int t = p.initSample; t < tEnd; t++) {
+    for (int t = p.initSample; t < tEnd; t++)
+    for (int q = 0; q < nq; q++) {
         const unsigned tag = (unsigned)(t - p.initSample) + 1u;
         const bool dumpNow = DUMP && p.dump && (t == tEnd - 1);
+        const int tile = cp.tile0 + q * cp.chains + chainIdx;
+        const int b = tile * 16 + j;
+        const bool uvalid = b < p.batch;
+        const int ub = uvalid ? b : p.batch - 1;
+        const unsigned long long* const skin = mstage + (size_t)q * (CC::XG + CC::SG) + CC::XG;
         int sb = tile * 16 + su;
         const bool sbValid = sb < p.batch;
         sb = sbValid ? sb : p.batch - 1;
         const float selv = p.useRng ? philox_selector(p.rngKey0, p.rngKey1, (unsigned)t, (unsigned)sb)
                                     : p.sel[(size_t)t * p.maxBatch + sb];
+        const int yCur = hist[(q * 2 + 1) * 16 + j];
 
         // ---- skip sums of all layers arrive; + biases, ReLU -> B fragments -----------------------------
 #pragma unroll
@@ -829,14 +874,13 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
         WN_CT(2)
 
         // ---- softmax + pick ------------------------------------------------------------------------
+        int pickKeep;
         {
             float e[C::RPL];
             float total;
             const int pick = softmax_pick<A, C::LPU, C::RPL>(lgbuf + su * C::LROW + sq * C::RPL, sq, lane, selv, e, total);
-            if (sq == 0) {
-                ybuf[su] = pick;
-                if (sbValid) p.yOut[(size_t)sb * p.numSamples + t] = pick;
-            }
+            if (sq == 0) ybuf[su] = pick;
+            pickKeep = pick;
             if (dumpNow && sbValid) {
                 const float inv = 1.0f / total;
 #pragma unroll
@@ -847,16 +891,29 @@ WN_DEV void chain_head(const Params& p, const ChainParams& cp, char* lds, int ti
         }
         wg_barrier();
         WN_CT(3)
-        yPrev = yCur;
-        yCur = ybuf[j];
-        if (t + 1 < tEnd) embed_and_send(tag + 1u);
+        const int yNew = ybuf[j];
+        // (every thread writes the values of its own column j and reads them back at the tile's next visit: no barrier needed)
+        hist[(q * 2 + 0) * 16 + j] = yCur;
+        hist[(q * 2 + 1) * 16 + j] = yNew;
+        if (t + 1 < tEnd) embed_and_send(q, tag + 1u, yNew);
+        if (sq == 0 && sbValid) p.yOut[(size_t)sb * p.numSamples + t] = pickKeep;      // (behind the hand-off: see chain_layers)
         WN_CT(4)
         WN_CT_FLUSH(stage, t - p.initSample)
-        // ybuf / lgbuf / skbuf are next written after the next sample's barriers
+        // ybuf / lgbuf / skbuf are next written after the next unit's barriers
     }
-    if (w == 0 && g == 0 && uvalid) {
-        p.yInPrev[ub] = yPrev;
-        p.yInCur[ub] = yCur;
+    if (probe) {
+        p.clk[2] = __builtin_amdgcn_s_memtime();
+        p.clk[3] = __builtin_amdgcn_s_memrealtime();
+    }
+    __syncthreads();
+    if (w == 0 && g == 0) {
+        for (int q = 0; q < nq; q++) {
+            const int b0 = (cp.tile0 + q * cp.chains + chainIdx) * 16 + j;
+            if (b0 < p.batch) {
+                p.yInPrev[b0] = hist[(q * 2 + 0) * 16 + j];
+                p.yInCur[b0] = hist[(q * 2 + 1) * 16 + j];
+            }
+        }
     }
 }
 
@@ -895,9 +952,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, 1>::THREADS), 1) void wavenet_ch
     const int stage = q % cp.stages;
     const int chainIdx = (q / cp.stages) * 8 + xcd;
     if (chainIdx >= cp.chains) return;
-    const int tile = cp.tile0 + chainIdx;
-    if (stage == cp.stages - 1) chain_head<F16, R, S, A, DUMP>(p, cp, lds, tile, chainIdx);
-    else chain_layers<F16, R, S, A, DUMP>(p, cp, lds, tile, chainIdx, stage);
+    if (stage == cp.stages - 1) chain_head<F16, R, S, A, DUMP>(p, cp, lds, chainIdx);
+    else chain_layers<F16, R, S, A, DUMP>(p, cp, lds, chainIdx, stage);
 }
 
 }  // namespace wn

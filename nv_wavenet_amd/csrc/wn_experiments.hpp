@@ -49,12 +49,6 @@
 #ifndef WN_FEAT_AUX
 #define WN_FEAT_AUX 0        // upsampled features (in-kernel conditioning): every wave of a workgroup reads the same fragments
 #endif
-#ifndef WN_BC_LD_AUX
-#define WN_BC_LD_AUX " nt"   // wavenet_bcast: conditioning / tap loads (instruction modifier text)
-#endif
-#ifndef WN_BC_ST_AUX
-#define WN_BC_ST_AUX " nt"   // wavenet_bcast: ring stores
-#endif
 
 // ---- ablations: TIMING ONLY -- the samples are wrong with any of them (none is defined in a product build) -------------------
 //   wavenet_wg   WN_ABL_NOACT          gate without transcendentals        WN_ABL_NOWEIGHTLOAD  no weight refills
@@ -62,12 +56,6 @@
 //                WN_ABL_HOTLOADS / WN_ABL_HOTTAPS / WN_ABL_HOTCOND         taps / conditioning always from the same, L2-resident rows
 //                WN_ABL_NOTAPGEMM      the tap GEMM's MFMAs not issued     WN_ABL_NOBARRIER     no workgroup barriers
 //                WN_ABL_NOHEADRES      no resident head matrix
-//   wavenet_bcast WN_BC_ABL_NODMA      no weight copies                    WN_BC_ABL_NOBAR      no chunk barriers / waits
-//                WN_BC_ABL_NOWAITB     barriers without the wait for the copies
-//                WN_BC_ABL_NOFIFO      no fragment reads from LDS          WN_BC_ABL_NOREQ      no conditioning / tap loads, no ring stores
-//                WN_BC_ABL_NOLOADS / WN_BC_ABL_NOSTORE                     only the loads / only the stores of those removed
-//                WN_BC_ABL_HOT         conditioning / taps always from the same, L2-resident rows
-//                WN_BC_WAITU=<n>       another count for the conditioning wait
 // ---- probes (results stay right) ------------------------------------------------------------------------------------------
 //   WN_TIMING        wavenet_wg: per-phase shader-clock sums of wave 0 into Params::p (scripts/quick_phase.py)
 //   WN_CHAIN_TIMING  wavenet_chain: wall-clock stamps per stage (scripts/chain_phase.py)

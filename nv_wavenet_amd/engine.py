@@ -30,9 +30,8 @@ class Org:
     WG3 = 4         # three tiles per workgroup (fp16, R <= 64; else two)
     CHAIN = 5       # wn::wavenet_chain: multi-CU, weights resident, fewest CUs
     CHAIN1 = 6      # wn::wavenet_chain, one layer per CU
-    BCAST = 7       # wn::wavenet_bcast: one whole tile per wave, weights broadcast through an LDS ring
-    BCAST1 = 8
-    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6, "bcast": 7, "bcast1": 8}
+    # (7, 8, 9 were wn::wavenet_bcast and its variants, removed in round 5: refused by nvw_create_ex)
+    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6}
 
 
 def supported_configs():

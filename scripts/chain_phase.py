@@ -29,8 +29,19 @@ def main():
         assert e.run(N, B, None, 1, False)
         e.synchronize()
     assert e.chainStatus() == 0
-    raw = e.getP().view(np.uint64).reshape(-1)[:K * 8 * 16].reshape(K, 8, 16).astype(np.int64)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    chains = min(ncu // K, (B + 15) // 16)
+    nq = -(-((B + 15) // 16) // chains)                   # tiles of chain 0
+    allq = e.getP().view(np.uint64).reshape(-1)[:K * nq * 8 * 16].reshape(K, nq, 8, 16).astype(np.int64)
     us = lambda a: a * 0.01
+    if nq > 1:
+        # several tiles per chain: when does every stage see the tiles of chain 0, relative to tile 0's arrival (sample 8..15 mean)
+        for s in range(K):
+            ev = 1 if s == K - 1 else 2                   # head: skip received; layer stage: x received
+            line = "  ".join("q%d +%.2f (busy %.2f)" % (q, us((allq[s, q, :, ev] - allq[s, 0, :, ev]).mean()),
+                                                        us((allq[s, q, :, 4 if s == K - 1 else 7] - allq[s, q, :, 0]).mean())) for q in range(nq))
+            print("stage %2d arrivals: %s" % (s, line))
+    raw = allq[:, 0]
     names = ["idle work", "wait x", "layers", "send x", "wait skip", "skip gemm", "send skip"]
     tot = us(np.diff(raw[K - 1, :, 3]).mean())
     print("sample period (head pick to pick): %.2f us" % tot)

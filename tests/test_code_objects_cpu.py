@@ -45,10 +45,10 @@ def test_production_kernels_of_the_fp16_engines_use_no_scratch(obj):
         pytest.skip("build the library first (__graft_entry__.build())")
     rows = kernel_table(obj)
     assert len(rows) >= 10, rows
-    gen = [r for r in rows if "wavenet_wg<" in r[0] or "wavenet_chain<" in r[0] or "wavenet_bcast<" in r[0]]
+    gen = [r for r in rows if "wavenet_wg<" in r[0] or "wavenet_chain<" in r[0]]
     assert gen, "no generation kernel in " + obj
     for name, vgpr, agpr, sgpr, scratch, spill in gen:
-        # the last-but-one bool of wavenet_wg / the last of wavenet_chain and wavenet_bcast is DUMP
+        # the last-but-one bool of wavenet_wg / the last of wavenet_chain is DUMP
         flags = name[name.index("<") + 1:name.rindex(">")].replace(" ", "").split(",")
         dump = flags[-2] if "wavenet_wg<" in name else flags[-1]
         assert vgpr <= 512 and agpr <= 256 and sgpr <= 106, (name, vgpr, agpr, sgpr)

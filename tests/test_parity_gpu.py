@@ -21,19 +21,11 @@ def _bspb(B):
 # the kernel organisations: wavenet_wg with one / two / three tiles of 16 utterances per workgroup (wn_kernels.hpp; the engine
 # picks by batch size: beyond one / two tiles per CU) and the multi-CU chain with resident weights (wn_chain.hpp; "chain": as
 # many layers per CU as stay resident, "chain1": one layer per CU)
-# ... and wn::wavenet_bcast (wn_bcast.hpp, round 4): every wave runs the whole network for its own tile, the weights broadcast
-# through an LDS ring ("bcast": four tiles per workgroup)
-MODES = ["wg", "wg2", "chain", "bcast"]
+# (wn::wavenet_bcast of rounds 3-4 -- every wave its own tile, weights broadcast through an LDS ring -- was removed in round 5)
+MODES = ["wg", "wg2", "chain"]
 ALL_MODES = MODES + ["chain1"]
-FP16_MODES = ["wg", "wg2", "wg3", "chain", "chain1", "bcast"]
-KERNEL_OF = {"wg": "wavenet_wg<", "wg2": "wavenet_wg<", "wg3": "wavenet_wg<", "chain": "wavenet_chain<", "chain1": "wavenet_chain<",
-             "bcast": "wavenet_bcast<"}
-
-
-def _bcast_shape(shape, precision=16):
-    """shapes wn::wavenet_bcast exists for (BCfg::SUPPORTED + the engine's depth check); others run wavenet_wg.  (fp32, S = 128:
-    layer and head parts of the stream share no ring length of at least 8 positions.)"""
-    return shape.R == 64 and shape.A <= 256 and shape.L >= 3 and (shape.S == 256 or (shape.S == 128 and precision == 16))
+FP16_MODES = ["wg", "wg2", "wg3", "chain", "chain1"]
+KERNEL_OF = {"wg": "wavenet_wg<", "wg2": "wavenet_wg<", "wg3": "wavenet_wg<", "chain": "wavenet_chain<", "chain1": "wavenet_chain<"}
 
 
 def _check_mode(e, mode, shape, precision=32):
@@ -41,9 +33,6 @@ def _check_mode(e, mode, shape, precision=32):
     (the chain does not exist for shapes whose single layer exceeds a CU: R = 256)."""
     info = e.kernelInfo()
     if mode in ("chain", "chain1") and shape.R >= 256:
-        assert "wavenet_wg<" in info, info
-        return
-    if mode == "bcast" and not _bcast_shape(shape, precision):
         assert "wavenet_wg<" in info, info
         return
     assert KERNEL_OF[mode] in info, (mode, info)
@@ -236,7 +225,7 @@ def test_fp16_engine_against_the_oracle_o1(name, mode, record_property):
 @pytest.mark.parametrize("name", ["C2", "C3", "C4"])
 def test_fp16_organisations_are_bit_identical_o1(name):
     """Same arithmetic in the same order in every organisation: the free-running fp16 samples are IDENTICAL."""
-    ys = {m: _fp16_checked_run(name, m)[1] for m in (["wg", "chain"] if name == "C4" else ["wg", "wg3", "chain", "bcast"])}
+    ys = {m: _fp16_checked_run(name, m)[1] for m in (["wg", "chain"] if name == "C4" else ["wg", "wg3", "chain"])}
     first = ys.pop("wg")
     for m, y in ys.items():
         assert np.array_equal(first, y), "wavenet_wg and %s disagree in fp16" % m
@@ -286,6 +275,43 @@ def test_chain_fills_the_gpu_by_replication():
     e.synchronize()
     assert e.chainStatus() == 0 and e.chainFallbacks() == 0
     bad = np.argwhere((y != y16[idx]).any(axis=1))
+    assert bad.size == 0, "utterance %d differs" % int(bad[0, 0])
+    e.close()
+
+
+@pytest.mark.parametrize("name,tpc,precision", [("C3", 3, 16), ("C4", 5, 16), ("C4", 8, 16), ("C3", 2, 32)])
+def test_chain_with_several_tiles_per_chain(name, tpc, precision):
+    """Round 5: batches beyond the chains that are resident at once ride the same chains, `tpc` tiles per chain (every stage works
+    through its chain's tiles in turn; role of the reference's persistent blocks looping over the whole batch,
+    nv_wavenet_persistent.cuh:110).  Ragged: the last chains hold one tile fewer and the last tile is partial.  Every utterance
+    must repeat, bit for bit, what the one-tile kernel generates for the case's utterances alone (which the oracle holds)."""
+    import torch
+    import re
+    case = O1_CASES[name]
+    s = case.shape
+    if name == "C4":
+        case = case._replace(shape=s._replace(N=160))
+        s = case.shape
+    t = util.gen_o1(case, half=precision == 16)
+    e0 = _engine_o1(case, t, precision, "wg")
+    y0 = _run_dumped(e0, case)["y"]
+    e0.close()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    probe = _engine_o1(case, t, precision, "chain")
+    stages = int(re.search(r"stages=(\d+)", probe.kernelInfo()).group(1))
+    probe.close()
+    chains = ncu // stages
+    tiles = chains * tpc - chains // 2                   # the upper half of the chains gets tpc - 1 tiles
+    B = 16 * tiles - 5                                   # ragged last tile
+    idx = np.arange(B) % s.B
+    e = _engine_o1(case, t, precision, "chain", B=B, Lh=np.ascontiguousarray(t.Lh[:, :, idx, :]), sel=np.ascontiguousarray(t.sel[:, idx]))
+    info = e.kernelInfo(B, False)
+    assert "wavenet_chain<" in info and "chains=%d tiles/chain=%d " % (chains, tpc) in info, info
+    y = np.full((B, s.N), -1, dtype=np.int32)
+    assert e.run_chunks(case.chunk, None, s.N, B, y, 1)
+    e.synchronize()
+    assert e.chainStatus() == 0 and e.chainFallbacks() == 0
+    bad = np.argwhere((y != y0[idx]).any(axis=1))
     assert bad.size == 0, "utterance %d differs" % int(bad[0, 0])
     e.close()
 
@@ -437,8 +463,7 @@ def test_conditioning_consumed_in_place(mode, precision):
     e.close()
 
 
-@pytest.mark.parametrize("mode,precision", [("wg", 32), ("chain", 32), ("bcast", 32), ("wg", 16), ("wg2", 16), ("wg3", 16), ("chain", 16),
-                                            ("bcast", 16)])
+@pytest.mark.parametrize("mode,precision", [("wg", 32), ("chain", 32), ("wg", 16), ("wg2", 16), ("wg3", 16), ("chain", 16)])
 def test_conditioning_produced_in_fragment_order(mode, precision):
     """Round 3: conditioning the caller PRODUCES in the engine's fragment order (setConditioningPacked; a model folds the
     channel permutation and the gate's pre-scale into its conditioning convolution, nv_wavenet.py: get_cond_input(layout=
@@ -621,16 +646,16 @@ def test_benchmarked_path_exactly(tiles_per_cu):
         y48 = sequence(3 * s.B, util.MODE_ORG["wg"])
         assert np.array_equal(y48[:s.B], y16)
         assert not np.array_equal(y48[s.B:2 * s.B], y16), "utterances 16.. drew utterance 0..'s selectors"
-        for mode in ("wg3", "bcast"):
+        for mode in ("wg3",):
             assert np.array_equal(sequence(3 * s.B, util.MODE_ORG[mode]), y48), "%s differs from the one-tile kernel on the benchmarked sequence" % mode
         return
     # the headline batch (the engine's own choice: three tiles per workgroup, the kernel bench.py asserts): its first 1024
     # utterances against the one-tile kernel run on 1024 utterances, whose first 16 are the oracle-held ones of the other case
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     B = tiles_per_cu * 16 * ncu
-    # (four tiles per CU: one round of wn::wavenet_bcast workgroups on every CU -- the full-load stress of its LDS ring protocol;
-    #  eight: whole rounds of three-tile wavenet_wg workgroups again -- the launch shapes of bench.py's `oversubscribed` entry)
-    y = sequence(B, 0, "wn::wavenet_bcast<fp16,64,256,256,BTW=1,EMBLDS=1,DUMP=0>" if tiles_per_cu == 4 else bench.HEADLINE_KERNELS[3])
+    # (four and eight tiles per CU: whole rounds of three-tile wavenet_wg workgroups -- the launch shapes of bench.py's
+    #  `oversubscribed` entry)
+    y = sequence(B, 0, bench.HEADLINE_KERNELS[3])
     y1k = sequence(1024, util.MODE_ORG["wg"])
     assert np.array_equal(y[:1024], y1k), "the headline batch differs from the one-tile kernel on the benchmarked sequence"
     assert np.array_equal(y1k[:s.B], sequence(s.B, util.MODE_ORG["wg"]))
@@ -1019,10 +1044,8 @@ def test_full_chip_batches_by_replication_fp16(B, impl):
     tiles = (B + 15) // 16
     info = e.kernelInfo(B, False)
     assert "DUMP=0" in info and "fp16" in info, info
-    # ... and between three and four tiles per CU one round of wn::wavenet_bcast workgroups (beyond: rounds of three-tile workgroups)
-    bc = impl == 0 and 3 * ncu < tiles <= 4 * ncu
-    want = "BTW=1" if bc else "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
-    assert want in info and ("wavenet_bcast<" in info) == bc, (info, ncu)
+    want = "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
+    assert want in info and "wavenet_wg<" in info, (info, ncu)
     y = np.full((B, s.N), -1, dtype=np.int32)
     assert e.run(s.N, B, y, 1, False)
     e.synchronize()
