@@ -327,6 +327,44 @@ def end_to_end_khz(w, B, chunk=256, chunks=4, seed=21):
     return (N / ms) if ok else 0.0
 
 
+UP_STRIDE, UP_WINDOW = 256, 1024             # upsampling of the synthetic model (the reference's is 200 / 800: the same four taps)
+
+
+def features_in_khz(w, B, chunk=256, chunks=4, seed=41):
+    """The deployable loop of round 5: FEATURES IN, SAMPLES OUT through one C-ABI call (nvw_generate_stream).  The engine holds the
+    model's `upsample` and `cond_layers` (pytorch/wavenet.py:70-74); per chunk of `chunk` samples it upsamples the mel-like frames
+    [B][80][frames] (fp16) with its own MFMA kernel into feature fragments, runs the generation launch -- which computes the
+    conditioning itself, wavenet_wg<.., RAW=3> -- and copies the chunk's samples out on a second stream.  Nothing else touches the
+    GPU: no [N][L][B][2R] tensor exists.  Wall clock around the call; returns (kHz per utterance, kernel)."""
+    import torch
+    N = chunk * chunks
+    e = build_engine(w, B, N)
+    Wc, bc = make_cond_layers()
+    e.setConditioningWeights(Wc, bc)
+    rng = np.random.default_rng(seed)
+    up_w = ((rng.random((N_COND, N_COND, UP_WINDOW), dtype=np.float32) - 0.5) * (np.sqrt(12.0) / np.sqrt(4 * N_COND))).astype(np.float32)
+    e.setUpsampling(up_w, np.zeros(N_COND, dtype=np.float32), UP_STRIDE)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    mel = torch.randn(B, N_COND, N // UP_STRIDE, device="cuda", generator=g).half()
+    e.setSelectorSeed(seed)
+    y = torch.zeros(B, N, dtype=torch.int32, device="cuda")
+    e.setMel(mel)
+    assert e.generate_stream(min(64, chunk), None, min(64, chunk), B, None)       # warm-up (code objects, buffers)
+    e.setMel(mel)                                                                 # (history back to the start)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ok = e.generate_stream(chunk, None, N, B, y)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    info = e.kernelInfo(B, False)
+    ok = ok and int(torch.unique(y).numel()) > 8 and "RAW=3" in info
+    e.close()
+    del mel, y
+    torch.cuda.empty_cache()
+    return ((N / ms) if ok else 0.0), info
+
+
 def with_producer_khz(w, B, chunk=256, chunks=4, seed=31):
     """The deployable loop with the conditioning PRODUCER in it (VERDICT r3 #3 i): a WaveNet's conditioning is the output of its
     own upsampling + 1x1 `cond_layers` convolution (pytorch/wavenet.py:190-202).  Per chunk of `chunk` samples,
@@ -604,6 +642,14 @@ def main():
                     lo = mid
                 else:
                     hi = mid
+            # the chosen batch three more times: it must hold 24 kHz in every probe, else one notch (16 tiles) down -- a box 3 % slower
+            # than the next must not flip the headline between runs
+            while lo > 16:
+                reps = [measure_steady_khz(w, 16 * lo)[0] for _ in range(3)]
+                sweep["%d (3 more probes)" % (16 * lo)] = reps
+                if min(reps) >= REALTIME_KHZ:
+                    break
+                lo -= 16
             choice[0] = 16 * lo
         if world > 1:
             if args.backend != "nccl":
@@ -700,19 +746,46 @@ def main():
         e2e["max_realtime_batch_per_gpu"] = best
         # ... and with the producer of that conditioning in the loop (the model's own upsampling + conditioning convolution, run on
         # the GPU between the generation launches, landing in fragment order): what a deployment gets end to end
-        wp = {"definition": "per chunk of 256 samples: get_cond_input(layout='packed') (upsampling of [B][80][frames] fp16 features as matrix "
+        fin = {"definition": "FEATURES IN, SAMPLES OUT (round 5): one nvw_generate_stream call over mel-like frames [B][80][frames] fp16 resident in "
+                             "HBM; per chunk of 256 samples the engine upsamples them with its own MFMA kernel (ConvTranspose1d, window 1024 / "
+                             "stride 256) into 160 B of features per utterance and sample, and the generation launch computes the conditioning "
+                             "Lh = Wcond c + bcond itself (wn::wavenet_wg<.., RAW=3>); samples copied out per chunk on a second stream; wall "
+                             "clock around the call, 4 chunks from sample 0", "sweep_khz": {}}
+        best_fin = None
+        for cand in sorted(set([B + 16 * ncu // 4, B, B - 16 * ncu // 4, B - 16 * ncu // 2, B * 3 // 4, B // 2]), reverse=True):
+            cand = max(16, cand // 64 * 64)
+            if cand > 48 * ncu or str(cand) in fin["sweep_khz"]:
+                continue
+            if extras_left() < 20:
+                skipped.append("end_to_end.with_producer.%d" % cand)
+                break
+            note("with_producer (features in) %d" % cand)
+            ks = []
+            for _ in range(3 if best_fin is None else 1):                      # three probes: a 3 % box must not flip the entry
+                k, info_fin = features_in_khz(w, cand)
+                ks.append(k)
+            fin["sweep_khz"][str(cand)] = ks
+            if min(ks) >= REALTIME_KHZ:
+                best_fin = cand
+                fin["kernel"] = info_fin.split(" ")[0]
+                fin["khz_per_utterance"] = min(ks)
+                fin["realtime_margin"] = min(ks) / REALTIME_KHZ - 1.0
+                break
+        fin["max_realtime_batch_per_gpu"] = best_fin
+        e2e["with_producer"] = fin
+        wp = {"definition": "(round 4's producer, kept for comparison) per chunk of 256 samples: get_cond_input(layout='packed') (upsampling of [B][80][frames] fp16 features as matrix "
                             "products, then the 1x1 conditioning convolution -- the engine's channel order and gate pre-scale folded into its "
                             "weights -- by the engine's own MFMA producer kernel, nvw_produce_conditioning_f16) writes the engine's fragment "
                             "order in place, then the generation launch "
                             "of that chunk; same stream (every CU holds a generation workgroup for a whole launch); 4 chunks, the first "
                             "production inside the timed region", "sweep_khz": {}}
         best_wp = None
-        for cand in sorted(set([B, B * 3 // 4, B // 2, B * 3 // 8, B // 4] + [c for c in (32 * ncu, 28 * ncu) if c < B]), reverse=True):
+        for cand in sorted(set([28 * ncu, B // 2]), reverse=True):
             cand = max(16, cand // 64 * 64)
-            if extras_left() < 20:
-                skipped.append("end_to_end.with_producer.%d" % cand)
+            if extras_left() < 60:
+                skipped.append("end_to_end.with_lh_producer.%d" % cand)
                 break
-            note("with_producer %d" % cand)
+            note("with_lh_producer %d" % cand)
             try:
                 k = with_producer_khz(w, cand)
             except Exception as ex:             # (e.g. out of memory in the producer's workspaces at the largest batch: an entry beside the headline must not take the run down)
@@ -724,7 +797,7 @@ def main():
                 best_wp = cand
                 break
         wp["max_realtime_batch_per_gpu"] = best_wp
-        e2e["with_producer"] = wp
+        e2e["with_lh_producer"] = wp
         # ... and with no pack at all: the kernels read the caller's tensor in place (setConditioningDirect), fp16 (the
         # engine's T_data) or fp32; steady state like the headline, at the headline batch, then at two / one tile per CU
         # until it is real time
@@ -830,19 +903,35 @@ def main():
         traffic, lds_counter, traffic_file = None, None, None
         # HBM and LDS bytes per launch from the PMC passes of the latest profiled round (profiles/traffic_rNN.json, written
         # by scripts/make_profiles_r*.py from rocprofv3 counters); only valid for the launch shape it was measured on
+        # ... AND for the device code it was measured on: the file carries the kernel's name and the sha256 of its instruction stream
+        # (scripts/isa_stats.py sha); a kernel that has changed since drops the counters (the algorithmic bytes are reported, and why)
         import glob
+        traffic_note = "no counter file for this launch shape (batch %d, %d samples): algorithmic bytes only" % (B, N)
+        sha_now = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import isa_stats
+            sub = isa_stats.kernel_sub_of(kname)
+            sha_now = isa_stats.kernel_sha("inst_%d_%d_%d_p16.o" % (HEAD.R, HEAD.S, HEAD.A), sub) if sub else None
+        except Exception:
+            sha_now = None
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
             try:
                 tj = json.load(open(tf))
                 if tj.get("batch") == B and tj.get("samples") == N:
+                    if tj.get("kernel") != kname or not sha_now or tj.get("kernel_sha256") != sha_now:
+                        traffic_note = ("%s was measured on %s, code %s; this run launches %s, code %s: counters dropped" %
+                                        (os.path.relpath(tf, ROOT), tj.get("kernel"), str(tj.get("kernel_sha256"))[:12], kname, str(sha_now)[:12]))
+                        break
                     traffic = tj.get("hbm_bytes_per_launch")
                     lds_counter = tj.get("lds_bytes_per_launch")
                     traffic_file = os.path.relpath(tf, ROOT)
+                    traffic_note = "rocprofv3 counters of this launch shape and this device code (%s)" % traffic_file
                     break
             except Exception:
                 pass
         roofline = dict(bound="mfma", achieved=flops / (kern_ms * 1e-3) / 1e12, peak=MFMA_F16_PEAK_TFLOPS,
-                        unit="TFLOP/s", traffic=traffic, kernel=kname, launch=kinfo,
+                        unit="TFLOP/s", traffic=traffic, traffic_source=traffic_note, kernel=kname, kernel_sha256=sha_now, launch=kinfo,
                         kernel_ms=kern_ms,
                         hbm=dict(achieved=units * HEAD.hbm_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"))
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
@@ -891,7 +980,7 @@ def main():
                                              "(setInputs outside the timed region, like the reference's harness); see end_to_end for "
                                              "conditioning streamed per chunk or read in place",
             "realtime_margin": khz / REALTIME_KHZ - 1.0,
-            "realtime_sweep_khz": {str(k): v for k, v in sorted(sweep.items())},
+            "realtime_sweep_khz": {str(k): v for k, v in sorted(sweep.items(), key=lambda kv: str(kv[0]))},
             "c3_b16": {"khz_per_utterance": c3_b16_khz, "samples_per_sec": None if c3_b16_khz is None else 16e3 * c3_b16_khz},
             "reference_definition": refdef,
             "end_to_end": e2e,

@@ -149,6 +149,28 @@ int nvw_pack_features(nvw_engine* e, const void* x, int precision, long long b_s
                       int first_sample, int count, void* stream);
 int nvw_set_features(nvw_engine* e, const void* x, int precision, long long b_stride, long long c_stride, long long t_stride,
                      int num_samples);
+/* FEATURES IN, AUDIO OUT (round 5; role of pytorch/inference.py:40-62 around run_chunks, nv_wavenet.cuh:445-497).  The other half of
+ * WaveNet.get_cond_input -- the `upsample` ConvTranspose1d and the trimming of its tail, pytorch/wavenet.py:195-197 -- on the engine's
+ * own MFMA kernel, writing the feature fragments the generation kernel reads:
+ *   nvw_set_upsampling      upsample.weight [n_cond][n_cond][window] and .bias [n_cond] (fp32, host or device, copied); window a multiple
+ *                           of stride, at most 8 strides (the reference: 800 / 200); after nvw_set_conditioning_weights
+ *   nvw_set_mel             the utterances' frames before upsampling, device tensor of 16- or 32-bit floats addressed
+ *                           x[b*b_stride + c*c_stride + f*f_stride] ([B][n_cond][frames]: strides n_cond*frames, frames, 1); copied;
+ *                           frames * stride <= the engine's samples; resets the history like nvw_set_inputs (start of a batch)
+ *   nvw_upsample_features   samples [first_sample, first_sample + count) of the upsampled features, asynchronously on `stream`
+ *   nvw_generate_stream     the whole loop: per chunk of num_samples_per_chunk samples the upsampling, the generation launch, the copy of
+ *                           the chunk's samples to yOut ([batch][num_samples] int32, host or device; may be NULL) and of the int16 PCM to
+ *                           the buffer of nvw_set_audio_out on a second stream, and consume(yOut, first, count, user) on the calling
+ *                           thread; selectors: nvw_set_selector_seed / nvw_set_selectors.  Returns when the last chunk is consumed.
+ * All return 1 on success, 0 when refused. */
+int nvw_set_upsampling(nvw_engine* e, const float* up_w, const float* up_b, int window, int stride);
+int nvw_set_mel(nvw_engine* e, const void* mel, int precision, long long b_stride, long long c_stride, long long f_stride, int frames);
+int nvw_upsample_features(nvw_engine* e, int first_sample, int count, void* stream);
+/* debug getter: samples [first_sample, first_sample + count) of the engine's feature buffer (what nvw_pack_features / nvw_upsample_features
+ * wrote: fragment order, the engine's T_data, nvw_feature_elems(e, count) elements) -> dst (host or device); synchronises */
+void nvw_get_features(nvw_engine* e, void* dst, int first_sample, int count);
+int nvw_generate_stream(nvw_engine* e, int num_samples_per_chunk, nvw_consume_fn consume, void* user, int num_samples, int batch_size, int* yOut,
+                        void* stream);
 /* the selector half of nvw_set_inputs ([num_samples][batch] uniform draws, host or device); conditioning and history untouched */
 void nvw_set_selectors(nvw_engine* e, float* output_selectors, int num_samples);
 /* Multi-CU (wavenet_chain) launches need all their workgroups resident at once; when other work holds CUs a launch gives up

@@ -50,6 +50,11 @@ SIGNATURES = {
     "nvw_set_conditioning_features": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_size_t]),
     "nvw_pack_features": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
     "nvw_set_features": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]),
+    "nvw_set_upsampling": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int]),
+    "nvw_set_mel": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]),
+    "nvw_upsample_features": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "nvw_get_features": (None, [C.c_void_p, _fp, C.c_int, C.c_int]),
+    "nvw_generate_stream": (C.c_int, [C.c_void_p, C.c_int, CONSUME_FN, C.c_void_p, C.c_int, C.c_int, _fp, C.c_void_p]),
     "nvw_set_selectors": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_chain_status": (C.c_uint, [C.c_void_p]),
     "nvw_chain_fallbacks": (C.c_uint, [C.c_void_p]),

@@ -23,6 +23,12 @@ struct nvw_engine {
     virtual void packFeatures(const void*, int, long long, long long, long long, int, int, hipStream_t) = 0;
     virtual void setFeatures(const void*, int, long long, long long, long long, int) = 0;
     virtual int conditioningChannels() = 0;
+    virtual bool setUpsampling(const float*, const float*, int, int) = 0;
+    virtual int upsamplingStride() = 0;
+    virtual void getFeatures(void*, int, int) = 0;
+    virtual void setMel(const void*, int, long long, long long, long long, int) = 0;
+    virtual void upsampleFeatures(int, int, hipStream_t) = 0;
+    virtual bool run_stream(int, nvw_consume_fn, void*, int, int, int*, hipStream_t) = 0;
     virtual size_t condPackedElems(int) = 0;
     virtual void setSelectors(float*, int) = 0;
     virtual bool run_range(int, int, int, int, hipStream_t) = 0;
@@ -75,6 +81,14 @@ struct EngineImpl : nvw_engine {
     }
     void setFeatures(const void* x, int prec, long long bS, long long cS, long long tS, int n) override { eng.setFeatures(x, prec, bS, cS, tS, n); }
     int conditioningChannels() override { return eng.conditioningChannels(); }
+    bool setUpsampling(const float* W, const float* b, int window, int stride) override { return eng.setUpsampling(W, b, window, stride); }
+    int upsamplingStride() override { return eng.upsamplingStride(); }
+    void getFeatures(void* d, int first, int count) override { eng.getFeatures(d, first, count); }
+    void setMel(const void* mel, int prec, long long bS, long long cS, long long fS, int frames) override { eng.setMel(mel, prec, bS, cS, fS, frames); }
+    void upsampleFeatures(int first, int count, hipStream_t s) override { eng.upsampleFeatures(first, count, s); }
+    bool run_stream(int chunk, nvw_consume_fn fn, void* user, int n, int b, int* y, hipStream_t s) override {
+        return eng.run_stream(chunk, [fn, user](int* yo, int i, int c) { if (fn) fn(yo, i, c, user); }, n, b, y, s);
+    }
     size_t condPackedElems(int n) override { return eng.condPackedElems(n); }
     void setSelectors(float* sel, int n) override { eng.setSelectors(sel, n); }
     bool run_range(int i, int c, int n, int b, hipStream_t s) override { return eng.run_range(i, c, n, b, s); }

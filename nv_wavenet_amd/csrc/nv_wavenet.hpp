@@ -112,6 +112,11 @@ protected:
     int m_restreamN;
     int m_nCond;              // channels of the model's features (0: no conditioning weights handed over)
     bool m_featDirty;         // m_wblobF / m_biasF are behind m_wblob / m_bias / m_condW
+    elem* m_upTab;            // upsampling (setUpsampling): the ConvTranspose1d weight as MFMA A operands, [stride][5][m * KFC] fragments
+    float* m_upBias;          // its bias, [80] fp32
+    int m_upWindow, m_upStride;
+    elem* m_melFrag;          // the utterances' mel frames in fragment order (setMel), [m_melFrames][m_tiles][KFC] fragments
+    int m_melFrames, m_melCap;
     elem* m_feat;             // features packed by the engine (packFeatures), [maxSamples][m_tiles][KFC] fragments
     const void* m_featPtr;    // the features the runs read: m_feat or the caller's buffer in that order (setConditioningFeatures)
     int m_featSamples;
@@ -348,6 +353,7 @@ public:
           m_maxSamples(numSamples), m_maxDilation(maxDilation), m_tanhEmbed(tanhEmbed),
           m_num_samples_per_chunk(0), m_lastStride(numSamples), m_cond(NULL), m_condRawSamples(0), m_condRaw(NULL), m_condRawKind(0), m_condUser(NULL), m_condUserSamples(0),
           m_wblobF(NULL), m_biasF(NULL), m_condW(NULL), m_condB(NULL), m_restream(NULL), m_restreamN(0), m_nCond(0), m_featDirty(true),
+          m_upTab(NULL), m_upBias(NULL), m_upWindow(0), m_upStride(0), m_melFrag(NULL), m_melFrames(0), m_melCap(0),
           m_feat(NULL), m_featPtr(NULL), m_featSamples(0),
           m_mail(NULL), m_chainStatus(NULL), m_mailBytes(0), m_ringShadow(NULL), m_histShadow(NULL),
           m_chainTimeoutTicks(wn::kChainTimeoutTicks), m_stage(NULL), m_stageElems(0), m_useRng(false), m_rngSeed(0), m_pcm(NULL),
@@ -471,6 +477,9 @@ public:
         if (m_condB) gpuErrChk(hipFree(m_condB));
         if (m_restream) gpuErrChk(hipFree(m_restream));
         if (m_feat) gpuErrChk(hipFree(m_feat));
+        if (m_upTab) gpuErrChk(hipFree(m_upTab));
+        if (m_upBias) gpuErrChk(hipFree(m_upBias));
+        if (m_melFrag) gpuErrChk(hipFree(m_melFrag));
         gpuErrChk(hipFree(m_outputSelectors));
         gpuErrChk(hipFree(m_ring));
         gpuErrChk(hipFree(m_yInPrev));
@@ -603,6 +612,137 @@ public:
         gpuErrChk(hipStreamSynchronize(0));
     }
     bool conditioningFromFeatures() const { return m_featPtr != NULL; }
+    // ---- ... and the upsampling in front of it (the other half of WaveNet.get_cond_input, pytorch/wavenet.py:195-197) -----------
+    // The model's `upsample` ConvTranspose1d: upW [nCond][nCond][window], upB [nCond], fp32, host or device, copied; window must be a
+    // multiple of stride (the reference's 800 / 200), at most 8 strides.  Needs setConditioningWeights first (the channel count).
+    static constexpr int kUpMaxTaps = 8;
+    bool setUpsampling(const float* upW, const float* upB, int window, int stride) {
+        if (m_nCond <= 0 || stride <= 0 || window < stride || window % stride != 0 || window / stride > kUpMaxTaps) return false;
+        const size_t nW = (size_t)m_nCond * m_nCond * window;
+        stageBegin(nW + 128);
+        if (m_upTab) gpuErrChk(hipFree(m_upTab));
+        const size_t tabElems = (size_t)stride * wn::kUpRowTiles * (window / stride) * KFC * C::FRAG_ELEMS;
+        gpuErrChk(hipMalloc(&m_upTab, tabElems * sizeof(elem)));
+        if (!m_upBias) gpuErrChk(hipMalloc(&m_upBias, wn::kUpRowTiles * 16 * sizeof(float)));
+        gpuErrChk(hipMemsetAsync(m_upBias, 0, wn::kUpRowTiles * 16 * sizeof(float), 0));
+        const float* dW = onDevice(upW, nW);
+        hipLaunchKernelGGL((wn::pack_upsample_kernel<F16>), dim3(gridFor(tabElems)), dim3(256), 0, 0, m_upTab, dW, m_nCond, window, stride);
+        gpuErrChk(hipGetLastError());
+        gpuErrChk(hipMemcpyAsync(m_upBias, upB, m_nCond * sizeof(float), hipMemcpyDefault, 0));
+        gpuErrChk(hipStreamSynchronize(0));
+        m_upWindow = window;
+        m_upStride = stride;
+        return true;
+    }
+    int upsamplingStride() const { return m_upStride; }
+    // debug getter: samples [firstSample, firstSample + count) of the engine's own feature buffer (fragment order, T_data) -> dst
+    void getFeatures(void* dst, int firstSample, int count) {
+        assert(m_feat != NULL && firstSample >= 0 && count > 0 && firstSample + count <= m_maxSamples);
+        gpuErrChk(hipDeviceSynchronize());
+        gpuErrChk(hipMemcpy(dst, m_feat + featureElems(firstSample), featureElems(count) * sizeof(elem), hipMemcpyDefault));
+    }
+    // The utterances' features before upsampling ("mel frames"): device tensor of `precision`-bit floats addressed
+    // x[b * bStride + c * cStride + f * fStride], frames <= maxSamples / stride; copied (into fragment order).  Resets the history like
+    // setInputs: the start of an utterance batch.
+    void setMel(const void* mel, int precision, long long bStride, long long cStride, long long fStride, int frames) {
+        assert(m_upStride > 0 && frames > 0 && (long long)frames * m_upStride <= m_maxSamples);
+        assert(isDevicePtr(mel) && (precision == 32 || precision == 16));
+        if (frames > m_melCap) {
+            if (m_melFrag) gpuErrChk(hipFree(m_melFrag));
+            m_melCap = m_maxSamples / m_upStride;
+            gpuErrChk(hipMalloc(&m_melFrag, featureElems(m_melCap) * sizeof(elem)));
+        }
+        resetHistory(0);
+        const int tilesUsed = (m_maxBatch + 15) / 16;
+        gpuErrChk(hipMemsetAsync(m_melFrag, 0, featureElems(frames) * sizeof(elem), 0));      // (tiles beyond the batch: zero frames)
+        const size_t nblk = (size_t)tilesUsed * ((frames + 7) / 8);
+        hipLaunchKernelGGL((wn::pack_features_kernel<F16>), dim3((unsigned)(nblk > 65536 ? 65536 : nblk)), dim3(256), 0, 0, m_melFrag, mel, precision,
+                           bStride, cStride, fStride, m_nCond, m_maxBatch, frames, m_tiles, tilesUsed);
+        gpuErrChk(hipGetLastError());
+        gpuErrChk(hipStreamSynchronize(0));
+        m_melFrames = frames;
+    }
+    // Samples [firstSample, firstSample + count) of the upsampled features from the frames handed over with setMel, into the engine's
+    // feature buffer, asynchronously on `stream` (one MFMA kernel: upsample_features_kernel); the runs that follow read them.
+    void upsampleFeatures(int firstSample, int count, hipStream_t stream = 0) {
+        assert(m_upStride > 0 && m_melFrames > 0);
+        assert(firstSample >= 0 && count > 0 && firstSample + count <= m_melFrames * m_upStride);
+        if (!m_feat) {
+            gpuErrChk(hipMalloc(&m_feat, featureElems(m_maxSamples) * sizeof(elem)));
+            gpuErrChk(hipMemsetAsync(m_feat, 0, featureElems(m_maxSamples) * sizeof(elem), stream));
+            gpuErrChk(hipStreamSynchronize(stream));
+        }
+        dropLhConditioning();
+        m_featPtr = m_feat;
+        m_featSamples = m_melFrames * m_upStride;
+        const int m = m_upWindow / m_upStride, tilesUsed = (m_maxBatch + 15) / 16;
+        const size_t lds = (size_t)wn::kUpRowTiles * m * KFC * 1024;
+        static bool allowed = false;
+        if (!allowed) {
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::upsample_features_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            allowed = true;
+        }
+        // a phase per workgroup; phases with few columns (long strides, short chunks) get more workgroups per phase
+        const int gx = m_upStride < 1024 ? m_upStride : 1024;
+        const long long cols = (long long)((count + m_upStride - 1) / m_upStride + 1) * tilesUsed;
+        int gy = (int)((cols + 63) / 64);
+        const int gyMax = (1024 + gx - 1) / gx;
+        if (gy > gyMax) gy = gyMax;
+        if (gy < 1) gy = 1;
+        hipLaunchKernelGGL((wn::upsample_features_kernel<F16>), dim3(gx, gy), dim3(256), lds, stream, m_feat, m_melFrag, m_upTab, m_upBias, m, m_upStride,
+                           m_tiles, tilesUsed, firstSample, count);
+        gpuErrChk(hipGetLastError());
+    }
+    // Features in, samples out (role of pytorch/inference.py:40-62 around run_chunks, nv_wavenet.cuh:445-497): the whole utterance
+    // batch chunk by chunk -- upsampling of a chunk's features, its generation launch, the copy of its samples (and PCM) on a second
+    // stream, consume(yOut, first, count) on the calling thread -- from the frames handed over with setMel.  Selectors: the seed or
+    // table in force.  num_samples <= frames * stride.
+    template <class Callback>
+    bool run_stream(int num_samples_per_chunk, Callback consume, int num_samples, int batch_size, int* yOut = NULL, hipStream_t stream = 0) {
+        assert(num_samples_per_chunk > 0 && m_melFrames > 0 && num_samples <= m_melFrames * m_upStride);
+        struct Piece {
+            int first, count;
+            hipEvent_t generated, delivered;
+        };
+        std::vector<Piece> pieces;
+        for (int first = 0; first < num_samples; first += num_samples_per_chunk) {
+            Piece pc;
+            pc.first = first;
+            pc.count = num_samples - first < num_samples_per_chunk ? num_samples - first : num_samples_per_chunk;
+            gpuErrChk(hipEventCreateWithFlags(&pc.generated, hipEventDisableTiming));
+            gpuErrChk(hipEventCreateWithFlags(&pc.delivered, hipEventDisableTiming));
+            pieces.push_back(pc);
+        }
+        hipStream_t genStream = stream, outStream;
+        if (!genStream) gpuErrChk(hipStreamCreate(&genStream));
+        gpuErrChk(hipStreamCreate(&outStream));
+        bool ok = true;
+        for (size_t k = 0; k < pieces.size(); k++) {
+            const Piece& pc = pieces[k];
+            // (the generation kernel holds every CU for the length of its launch: the upsampling of a chunk runs in front of it on the
+            //  same stream -- 1 to 2 % of the chunk's time -- instead of beside it)
+            upsampleFeatures(pc.first, pc.count, genStream);
+            m_num_samples_per_chunk = pc.count;
+            ok = run_partial(pc.first, num_samples, batch_size, NULL, 1, false, genStream) && ok;
+            gpuErrChk(hipEventRecord(pc.generated, genStream));
+            gpuErrChk(hipStreamWaitEvent(outStream, pc.generated, 0));
+            if (yOut) getYOut(yOut, pc.first, pc.count, outStream);
+            if (m_pcmUser) getAudioOut(m_pcmUser, pc.first, pc.count, outStream);
+            gpuErrChk(hipEventRecord(pc.delivered, outStream));
+        }
+        m_num_samples_per_chunk = 0;
+        for (size_t k = 0; k < pieces.size(); k++) {
+            gpuErrChk(hipEventSynchronize(pieces[k].delivered));
+            consume(yOut, pieces[k].first, pieces[k].count);
+        }
+        for (size_t k = 0; k < pieces.size(); k++) {
+            gpuErrChk(hipEventDestroy(pieces[k].generated));
+            gpuErrChk(hipEventDestroy(pieces[k].delivered));
+        }
+        if (!stream) gpuErrChk(hipStreamDestroy(genStream));
+        gpuErrChk(hipStreamDestroy(outStream));
+        return ok;
+    }
     // col-major Wprev,Wcur 2RxR; Bh 2R; Wres RxR; Bres R; Wskip SxR; Bskip S (nv_wavenet.cuh:400-409)
     virtual void setLayerWeights(int layer, float* Wprev, float* Wcur, float* Bh, float* Wres, float* Bres,
                                  float* Wskip, float* Bskip) {

@@ -165,6 +165,35 @@ int nvw_pack_features(nvw_engine* e, const void* x, int precision, long long b_s
     e->packFeatures(x, precision, b_stride, c_stride, t_stride, first_sample, count, (hipStream_t)stream);
     return 1;
 }
+int nvw_set_upsampling(nvw_engine* e, const float* up_w, const float* up_b, int window, int stride) {
+    if (!e->setUpsampling(up_w, up_b, window, stride)) {
+        fprintf(stderr, "nvw_set_upsampling: window %d / stride %d (a multiple of the stride, at most 8 strides; nvw_set_conditioning_weights first)\n",
+                window, stride);
+        return 0;
+    }
+    return 1;
+}
+int nvw_set_mel(nvw_engine* e, const void* mel, int precision, long long b_stride, long long c_stride, long long f_stride, int frames) {
+    const int stride = e->upsamplingStride();
+    if (stride <= 0 || !devicePtr(mel) || (precision != 32 && precision != 16) || frames <= 0 || (long long)frames * stride > e->maxSamples()) {
+        fprintf(stderr, "nvw_set_mel: refused (nvw_set_upsampling first; device memory; 16- or 32-bit floats; frames * stride <= the engine's %d samples)\n",
+                e->maxSamples());
+        return 0;
+    }
+    e->setMel(mel, precision, b_stride, c_stride, f_stride, frames);
+    return 1;
+}
+int nvw_upsample_features(nvw_engine* e, int first_sample, int count, void* stream) {
+    if (e->upsamplingStride() <= 0 || first_sample < 0 || count <= 0) return 0;
+    e->upsampleFeatures(first_sample, count, (hipStream_t)stream);
+    return 1;
+}
+void nvw_get_features(nvw_engine* e, void* dst, int first_sample, int count) { e->getFeatures(dst, first_sample, count); }
+int nvw_generate_stream(nvw_engine* e, int num_samples_per_chunk, nvw_consume_fn consume, void* user, int num_samples, int batch_size, int* yOut,
+                        void* stream) {
+    if (e->upsamplingStride() <= 0 || num_samples_per_chunk <= 0 || num_samples <= 0) return 0;
+    return e->run_stream(num_samples_per_chunk, consume, user, num_samples, batch_size, yOut, (hipStream_t)stream) ? 1 : 0;
+}
 int nvw_set_features(nvw_engine* e, const void* x, int precision, long long b_stride, long long c_stride, long long t_stride,
                      int num_samples) {
     if (!featArgsOk(e, "nvw_set_features", x, 0, num_samples) || (precision != 32 && precision != 16)) return 0;

@@ -1903,6 +1903,90 @@ __global__ __launch_bounds__(256) void pack_features_kernel(typename Prec<F16>::
     }
 }
 
+// ---- the upsampling half of the model's conditioning path on the engine's own kernels (round 5) ------------------------------
+// WaveNet.get_cond_input (pytorch/wavenet.py:190-202) = ConvTranspose1d(n_cond, n_cond, window, stride) + trimming of its tail + the
+// 1x1 `cond_layers`; the latter is computed by wavenet_wg<.., RAW=3>, this is the former, straight into the feature fragments that
+// kernel reads:   c[t][co] = b[co] + sum_{j < m} sum_ci mel[ci][f - j] W[ci][co][j*stride + r],   t = f*stride + r, m = window / stride
+// (frames f - j < 0 contribute nothing; the trimmed output has frames * stride samples).  Per phase r this is a GEMM
+// [n_cond x m*n_cond] x [m*n_cond x columns] whose B operand for (frame f, tile) are the MEL fragments of frames f .. f-m+1 -- mel in
+// the same fragment order as the features (pack_features_kernel with frames for samples) -- and whose result tiles (MFMA D layout)
+// ARE feature fragments once converted to T_data.  A workgroup takes a phase: its operand A_r (RTU x m*KFC fragments) sits in LDS,
+// its four waves share the columns.
+constexpr int kUpRowTiles = (kCondChannelsMax + 15) / 16;
+// table of the A operands: [stride][kUpRowTiles][m * KFC][64 lanes][EPL] from the ConvTranspose1d weight [n_cond][n_cond][window]
+template <bool F16>
+__global__ void pack_upsample_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ upW, int nCond, int window, int stride) {
+    constexpr int KFC = feat_kfc<F16>(), TPF = Prec<F16>::TPF, EPL = Prec<F16>::EPL;
+    const int m = window / stride;
+    const size_t n = (size_t)stride * kUpRowTiles * m * KFC * 64 * EPL;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t q = idx;
+        const int e = (int)(q % EPL); q /= EPL;
+        const int lane = (int)(q % 64); q /= 64;
+        const int kfu = (int)(q % (m * KFC)); q /= (size_t)(m * KFC);
+        const int tr = (int)(q % kUpRowTiles);
+        const int r = (int)(q / kUpRowTiles);
+        const int j = kfu / KFC, kf = kfu % KFC, i = lane & 15, g = lane >> 4;
+        const int co = tr * 16 + i, ci = (kf * TPF + (e >> 2)) * 16 + 4 * g + (e & 3);
+        const float v = (co < nCond && ci < nCond) ? upW[((size_t)ci * nCond + co) * window + j * stride + r] : 0.f;
+        dst[idx] = (typename Prec<F16>::elem)v;
+    }
+}
+template <bool F16>
+__global__ __launch_bounds__(256) void upsample_features_kernel(typename Prec<F16>::elem* __restrict__ feat, const typename Prec<F16>::elem* __restrict__ melfrag,
+                                                                const typename Prec<F16>::elem* __restrict__ tab, const float* __restrict__ bias, int m,
+                                                                int stride, int tiles, int tilesUsed, int firstSample, int count) {
+    using P = Prec<F16>;
+    using frag = typename P::frag;
+    constexpr int KFC = feat_kfc<F16>(), EPL = P::EPL, RTU = kUpRowTiles;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4;
+    const int nA = RTU * m * KFC;                                     // fragments of one phase's operand
+    for (int r = blockIdx.x; r < stride; r += gridDim.x) {
+        __syncthreads();                                              // (the previous phase's readers are done)
+        const uintx4* src = (const uintx4*)(tab + (size_t)r * nA * 64 * EPL);
+        for (int i = tid; i < nA * 64; i += 256) ((uintx4*)lds)[i] = src[i];
+        __syncthreads();
+        // frames whose sample f*stride + r lies in [firstSample, firstSample + count)
+        int fLo = (firstSample - r + stride - 1) / stride;
+        if (fLo < 0) fLo = 0;
+        const int last = firstSample + count - 1 - r;
+        if (last < 0) continue;
+        const int fHi = last / stride;
+        const int ncol = (fHi - fLo + 1) * tilesUsed;
+        for (int col = blockIdx.y * 4 + w; col < ncol; col += gridDim.y * 4) {
+            const int f = fLo + col / tilesUsed, tile = col % tilesUsed, t = f * stride + r;
+            floatx4 acc[RTU];
+#pragma unroll
+            for (int tr = 0; tr < RTU; tr++) acc[tr] = *(const floatx4*)(bias + tr * 16 + g * 4);
+            for (int j = 0; j < m && j <= f; j++) {
+                const char* mf = (const char*)(melfrag + ((size_t)(f - j) * tiles + tile) * KFC * 64 * EPL);
+                frag b[KFC];
+#pragma unroll
+                for (int kf = 0; kf < KFC; kf++) b[kf] = *(const frag*)(mf + ((size_t)kf * 64 + lane) * 16);
+#pragma unroll
+                for (int kf = 0; kf < KFC; kf++)
+#pragma unroll
+                    for (int tr = 0; tr < RTU; tr++)
+                        acc[tr] = mma(*(const frag*)(lds + ((size_t)((tr * m + j) * KFC + kf) * 64 + lane) * 16), b[kf], acc[tr]);
+            }
+            typename P::elem* out = feat + ((size_t)t * tiles + tile) * KFC * 64 * EPL;
+#pragma unroll
+            for (int kf = 0; kf < KFC; kf++) {
+                frag o;
+                if constexpr (F16) {
+                    const floatx4 lo = acc[2 * kf], hi = (2 * kf + 1 < RTU) ? acc[2 * kf + 1 < RTU ? 2 * kf + 1 : 0] : floatx4{0.f, 0.f, 0.f, 0.f};
+                    o = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2],
+                              (_Float16)hi[3]};
+                } else {
+                    o = acc[kf < RTU ? kf : 0];
+                }
+                *(frag*)((char*)out + ((size_t)kf * 64 + lane) * 16) = o;
+            }
+        }
+    }
+}
+
 static __global__ void silence_kernel(int* yInPrev, int* yInCur, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         yInPrev[i] = 128;   // mu-law silence, nv_wavenet.cuh:213-218

@@ -205,6 +205,50 @@ class WavenetEngine:
         if not lib.nvw_set_conditioning_features(self._h, addr(frags), ns, frags.numel()):
             raise ValueError("the feature fragment tensor does not fit %d samples" % ns)
 
+    # ---- features in, samples out: the upsampling on the engine's own kernel and the streaming loop ---------------------------
+    def setUpsampling(self, upW, upB, stride):
+        """The model's `upsample` ConvTranspose1d (pytorch/wavenet.py:70-72): weight [n_cond][n_cond][window], bias [n_cond]."""
+        W, b = _f32(upW), _f32(upB)
+        window = int(W.shape[2])
+        assert tuple(W.shape[:2]) == (self.nCond, self.nCond), "upsample weight must be [n_cond][n_cond][window]"
+        if not lib.nvw_set_upsampling(self._h, addr(W), addr(b), window, int(stride)):
+            raise ValueError("upsampling window %d / stride %d not supported" % (window, stride))
+        self.upStride = int(stride)
+
+    def setMel(self, mel):
+        """The utterances' frames before upsampling: CUDA tensor [maxBatch][n_cond][frames], float32 or float16, any strides.  Copied;
+        resets the history (the start of an utterance batch)."""
+        bits, sb, sc, sf = self._feat_args(mel)
+        assert mel.size(0) == self.maxBatch and mel.size(1) == self.nCond
+        self._cond_keep = None
+        if not lib.nvw_set_mel(self._h, mel.data_ptr(), bits, sb, sc, sf, mel.size(2)):
+            raise ValueError("nvw_set_mel refused %s" % (tuple(mel.shape),))
+        self.melFrames = mel.size(2)
+
+    def upsampleFeatures(self, firstSample, count, stream=None):
+        assert lib.nvw_upsample_features(self._h, int(firstSample), int(count), stream)
+
+    def getFeatures(self, firstSample, count):
+        """Debug getter: the engine's own feature fragments of samples [firstSample, firstSample + count) as a CUDA tensor
+        [count][condTiles()][featureFragments()][4][16][8 | 4]."""
+        import torch
+        epl = 8 if self.precision == 16 else 4
+        out = torch.empty(count, self.condTiles(), self.featureFragments(), 4, 16, epl, device="cuda",
+                          dtype=torch.float16 if self.precision == 16 else torch.float32)
+        lib.nvw_get_features(self._h, out.data_ptr(), int(firstSample), int(count))
+        return out
+
+    def generate_stream(self, num_samples_per_chunk, consume, num_samples, batch_size, yOut=None, stream=None):
+        """Features in, samples out: per chunk the upsampling, the generation launch and the copy of the chunk's samples (and PCM);
+        consume(yOut, first, count) on this thread for every finished chunk."""
+        def _cb(_ptr, init, count, _user):
+            if consume is not None:
+                consume(yOut, init, count)
+        cb = CONSUME_FN(_cb)
+        self._cb_keep = cb
+        return bool(lib.nvw_generate_stream(self._h, int(num_samples_per_chunk), cb, None, int(num_samples), int(batch_size),
+                                            self._yout(yOut, num_samples), stream))
+
     def setSelectors(self, outputSelectors, numSamples=None):
         """The selector half of setInputs: [numSamples][maxBatch] uniform draws; conditioning and history untouched."""
         sel = _f32(outputSelectors)

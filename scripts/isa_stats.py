@@ -4,6 +4,9 @@
   isa_stats.py regs  [inst]                 registers / scratch / LDS of every kernel of an instantiation object
   isa_stats.py mix   [inst] <kernel-substr> instruction mix of the kernel whose demangled name contains the substring,
                                             whole kernel and its largest loop body (the per-sample loop of wavenet_wg)
+  isa_stats.py sha   [inst] <kernel-substr> sha256 of that kernel's disassembly (addresses stripped): the identity of the device code
+                                            a measurement belongs to (profiles/traffic_rNN.json; bench.py drops a measurement taken on
+                                            other code)
 
 inst: name of an object under nv_wavenet_amd/csrc/build (default inst_64_256_256_p16.o).
 """
@@ -126,8 +129,45 @@ def mix(inst, sub):
                 report("  per-sample loop outside the inner loop(s) (first layer, odd tail, head, softmax)", outer[0], outer[1], inner)
 
 
+def kernel_sha(inst, sub):
+    """sha256 over the instruction stream (mnemonics + operands, no addresses) of the ONE kernel whose demangled name contains `sub`;
+    None when the object is missing or the match is not unique."""
+    import hashlib
+    try:
+        co = code_object(inst)
+        dis = subprocess.run([LLVM + "llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True, timeout=600).stdout
+    except Exception:
+        return None
+    blocks = re.split(r"\n(?=[0-9a-f]+ <)", dis)
+    syms = []
+    for b in blocks:
+        m = re.match(r"[0-9a-f]+ <([^>]+)>:", b)
+        if m:
+            syms.append((m.group(1), b))
+    dm = demangle([s_ for s_, _ in syms])
+    hits = [b for s_, b in syms if sub in dm[s_].replace(" ", "")]
+    if len(hits) != 1:
+        return None
+    text = "\n".join(re.sub(r"\s*//.*$", "", ln).strip() for ln in hits[0].split("\n")[1:])
+    text = re.sub(r"<[^>]*>", "", text)              # (branch targets print as symbol+offset: keep the offset-free form)
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
+def kernel_sub_of(kernel_info_name):
+    """'wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0,RAW=0>' (nvw_kernel_info) -> the demangled-name substring of that kernel"""
+    m = re.match(r"wn::(\w+)<(fp16|fp32),(\d+),(\d+),(\d+),BT=(\d+),EMBLDS=(\d+),DUMP=(\d+),RAW=(\d+)>", kernel_info_name)
+    if not m:
+        return None
+    k, prec, r_, s_, a_, bt, emb, dump, raw = m.groups()
+    return "wn::%s<%s,%s,%s,%s,%s,%s,%s,%s>" % (k, "true" if prec == "fp16" else "false", r_, s_, a_, bt, "true" if int(emb) else "false",
+                                                   "true" if int(dump) else "false", raw)
+
+
 if __name__ == "__main__":
     a = sys.argv[1:]
+    if a and a[0] == "sha":
+        print(kernel_sha(a[1] if len(a) > 2 else "inst_64_256_256_p16.o", a[-1].replace(" ", "")))
+        sys.exit(0)
     if not a or a[0] not in ("regs", "mix"):
         sys.exit(__doc__)
     if a[0] == "regs":
