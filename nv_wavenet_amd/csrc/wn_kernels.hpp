@@ -1152,6 +1152,13 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 for (int k = 0; k < KFC; k++) cfCur[bt][k] = agpr_operand<F16>(cfNext[bt][k]);
             gemm_direct<F16, BT, 2 * HTW, KFC>(wbase + C::streamPos(0, C::O_COND, L) * 1024, laneOff, acc, cfCur);
             load_feat(p.initSample + 1, cfNext);
+            // ... and waited for HERE (an empty asm that reads them): a load still pending at the loop entry makes the compiler drain
+            // the whole queue (vmcnt(0): the weight ring with it) at the move behind layer L-2 of EVERY sample; from the loop's own
+            // requests -- a whole sample of loads ahead of their reader -- it knows they have landed
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int k = 0; k < KFC; k++) asm volatile("" ::"v"(cfNext[bt][k]));
         } else if constexpr (F16) {
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
@@ -1535,7 +1542,6 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 }
             }
         }
-        if constexpr (FEAT) load_feat(t + 2, cfNext);      // (its last reader was the move behind layer L-2)
         // skip GEMM of the last layer
         gemm_b<F16, PF, 0, BT, STW, KF_R>(ws, rsW, C::P_CUR, (L - 1) * FLW, 0, laneOff, skip, hb);
 
@@ -1637,6 +1643,10 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         if constexpr (HS == FHW) {
             skip_frags<F16, PF, C::HSP, ws_pin, C::PAD2>(ws, rsW, C::O_ZA + C::FW_ZA, L * FLW, 0, laneOff);   // (zero fragments)
         }
+        // FEAT: the features of sample t+2 (HBM) are requested HERE, behind the last take of the sample: loads return in order, and in
+        // front of the head's weight refills they would hold those up for an HBM round trip; their reader is the move behind layer
+        // L-2 of the next sample (the last reader of cfNext was that move of this sample)
+        if constexpr (FEAT) load_feat(t + 2, cfNext);
         wg_barrier();
         WN_TMARK(9)
 
@@ -1954,34 +1964,63 @@ __global__ __launch_bounds__(256) void upsample_features_kernel(typename Prec<F1
         if (last < 0) continue;
         const int fHi = last / stride;
         const int ncol = (fHi - fLo + 1) * tilesUsed;
-        for (int col = blockIdx.y * 4 + w; col < ncol; col += gridDim.y * 4) {
-            const int f = fLo + col / tilesUsed, tile = col % tilesUsed, t = f * stride + r;
-            floatx4 acc[RTU];
+        // CB columns per pass over the operand: an A fragment read from LDS feeds CB MFMAs (one column per pass is bound by the LDS:
+        // 60 KiB of operand reads per column, 0.40 ms per chunk of 256 samples x 12 288 utterances; four: 0.1 ms)
+        constexpr int CB = 4;
+        const int ngrp = (ncol + CB - 1) / CB;
+        for (int grp = blockIdx.y * 4 + w; grp < ngrp; grp += gridDim.y * 4) {
+            int fcol[CB], tcol[CB];
 #pragma unroll
-            for (int tr = 0; tr < RTU; tr++) acc[tr] = *(const floatx4*)(bias + tr * 16 + g * 4);
-            for (int j = 0; j < m && j <= f; j++) {
-                const char* mf = (const char*)(melfrag + ((size_t)(f - j) * tiles + tile) * KFC * 64 * EPL);
-                frag b[KFC];
+            for (int c = 0; c < CB; c++) {
+                const int col = grp * CB + c < ncol ? grp * CB + c : ncol - 1;      // (a partial group repeats its last column)
+                fcol[c] = fLo + col / tilesUsed;
+                tcol[c] = col % tilesUsed;
+            }
+            floatx4 acc[CB][RTU];
 #pragma unroll
-                for (int kf = 0; kf < KFC; kf++) b[kf] = *(const frag*)(mf + ((size_t)kf * 64 + lane) * 16);
+            for (int c = 0; c < CB; c++)
+#pragma unroll
+                for (int tr = 0; tr < RTU; tr++) acc[c][tr] = *(const floatx4*)(bias + tr * 16 + g * 4);
+            for (int j = 0; j < m; j++) {
+                frag b[CB][KFC];
+#pragma unroll
+                for (int c = 0; c < CB; c++) {
+                    const int fj = fcol[c] - j;
+                    const char* mf = (const char*)(melfrag + ((size_t)(fj < 0 ? 0 : fj) * tiles + tcol[c]) * KFC * 64 * EPL);
+#pragma unroll
+                    for (int kf = 0; kf < KFC; kf++) {
+                        b[c][kf] = *(const frag*)(mf + ((size_t)kf * 64 + lane) * 16);
+                        if (fj < 0) {                                   // (frames before the first contribute nothing)
+#pragma unroll
+                            for (int q = 0; q < EPL; q++) b[c][kf][q] = (typename P::elem)0.f;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int kf = 0; kf < KFC; kf++)
 #pragma unroll
-                    for (int tr = 0; tr < RTU; tr++)
-                        acc[tr] = mma(*(const frag*)(lds + ((size_t)((tr * m + j) * KFC + kf) * 64 + lane) * 16), b[kf], acc[tr]);
-            }
-            typename P::elem* out = feat + ((size_t)t * tiles + tile) * KFC * 64 * EPL;
+                    for (int tr = 0; tr < RTU; tr++) {
+                        const frag a = *(const frag*)(lds + ((size_t)((tr * m + j) * KFC + kf) * 64 + lane) * 16);
 #pragma unroll
-            for (int kf = 0; kf < KFC; kf++) {
-                frag o;
-                if constexpr (F16) {
-                    const floatx4 lo = acc[2 * kf], hi = (2 * kf + 1 < RTU) ? acc[2 * kf + 1 < RTU ? 2 * kf + 1 : 0] : floatx4{0.f, 0.f, 0.f, 0.f};
-                    o = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2],
-                              (_Float16)hi[3]};
-                } else {
-                    o = acc[kf < RTU ? kf : 0];
+                        for (int c = 0; c < CB; c++) acc[c][tr] = mma(a, b[c][kf], acc[c][tr]);
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < CB; c++) {
+                if (grp * CB + c >= ncol) continue;
+                typename P::elem* out = feat + ((size_t)(fcol[c] * stride + r) * tiles + tcol[c]) * KFC * 64 * EPL;
+#pragma unroll
+                for (int kf = 0; kf < KFC; kf++) {
+                    frag o;
+                    if constexpr (F16) {
+                        const floatx4 lo = acc[c][2 * kf], hi = (2 * kf + 1 < RTU) ? acc[c][2 * kf + 1 < RTU ? 2 * kf + 1 : 0] : floatx4{0.f, 0.f, 0.f, 0.f};
+                        o = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2],
+                                  (_Float16)hi[3]};
+                    } else {
+                        o = acc[c][kf < RTU ? kf : 0];
+                    }
+                    *(frag*)((char*)out + ((size_t)kf * 64 + lane) * 16) = o;
                 }
-                *(frag*)((char*)out + ((size_t)kf * 64 + lane) * 16) = o;
             }
         }
     }
