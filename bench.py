@@ -558,6 +558,9 @@ def main():
     ap.add_argument("--samples", type=int, default=0, help="samples per step (0 = auto)")
     ap.add_argument("--config", default="headline", choices=["headline", "c5"],
                     help="c5: BASELINE configs[4], global batch 64 sharded over the ranks (8 x 8 on 8 GPUs)")
+    ap.add_argument("--conditioning", default="packed", choices=["packed", "features"],
+                    help="what the timed launches read: conditioning pre-packed in fragment order (the reference harness's setInputs outside "
+                         "the timed region; the headline), or the upsampled features, the conditioning computed in the kernel (profiling aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip reference_definition / end_to_end / oversubscribed")
     ap.add_argument("--extras-budget", type=float, default=240.0,
@@ -827,7 +830,7 @@ def main():
     #      wrapped, conditioning rows of exactly those samples) for every utterance (re-run per step on the rings the previous step left:
     #      timing only, see config.workload)
     note("timed steps")
-    e, NTOT, _keep = steady_engine(w, B, N, 100 + rank)
+    e, NTOT, _keep = steady_engine(w, B, N, 100 + rank, "features" if args.conditioning == "features" else None)
     e.setClockProbe(True)                       # workgroup 0 of every launch records shader / wall clock counters
     kinfo = e.kernelInfo(B, False)
     torch.cuda.empty_cache()
@@ -897,7 +900,7 @@ def main():
         chain_mode = "wavenet_chain" in kname
         bt = 3 if "BT=3" in kname else 2 if "BT=2" in kname else 1
         if not args.batch and args.config == "headline" and tiles > ncu:
-            assert kname == HEADLINE_KERNELS[bt], kinfo     # the launches the parity tests pin
+            assert kname == HEADLINE_KERNELS[bt].replace("RAW=0", "RAW=3" if args.conditioning == "features" else "RAW=0"), kinfo     # the launches the parity tests pin
         # workgroups (weight-stream passes) per sample
         passes = (tiles + bt - 1) // bt
         traffic, lds_counter, traffic_file = None, None, None
@@ -930,10 +933,14 @@ def main():
                     break
             except Exception:
                 pass
+        # compulsory HBM bytes per utterance and sample: the conditioning (2R x L fp16 values) or, computed in the kernel, the features
+        # it is computed from (feature fragments: 96 fp16 values), + selector + sample
+        hbm_alg = (2 * 96 + 8) if args.conditioning == "features" else HEAD.hbm_bytes
         roofline = dict(bound="mfma", achieved=flops / (kern_ms * 1e-3) / 1e12, peak=MFMA_F16_PEAK_TFLOPS,
                         unit="TFLOP/s", traffic=traffic, traffic_source=traffic_note, kernel=kname, kernel_sha256=sha_now, launch=kinfo,
                         kernel_ms=kern_ms,
-                        hbm=dict(achieved=units * HEAD.hbm_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"))
+                        hbm=dict(achieved=units * hbm_alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                 bytes_per_utterance_sample=hbm_alg))
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         # measured inside the kernel (s_memtime ticks over s_memrealtime ticks of workgroup 0): under full load the chip
         # runs this launch below its 2.4 GHz maximum -- power-limited, profiles/r04_clock_*.json -- and `frac` is against the
@@ -946,8 +953,8 @@ def main():
         # ... and with the dilation ring, which this design keeps in HBM (read x[t-d], write x[t]: 2 x 2R bytes per layer, utterance and
         # sample): the bytes the kernel actually asks of the memory system (what `traffic` measures), and the roof it is nearest to
         ring_bytes = 2 * 2 * HEAD.R * HEAD.L
-        roofline["hbm_with_ring"] = dict(achieved=units * (HEAD.hbm_bytes + ring_bytes) / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                         bytes_per_utterance_sample=HEAD.hbm_bytes + ring_bytes)
+        roofline["hbm_with_ring"] = dict(achieved=units * (hbm_alg + ring_bytes) / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                         bytes_per_utterance_sample=hbm_alg + ring_bytes)
         roofline["hbm_with_ring"]["frac"] = roofline["hbm_with_ring"]["achieved"] / HBM_PEAK_GBS
         if not chain_mode:                                      # (the chain reads no weights after its prologue)
             roofline["l2_weight_stream"] = dict(achieved=passes * N * HEAD.weight_bytes / (kern_ms * 1e-3) / 1e9,

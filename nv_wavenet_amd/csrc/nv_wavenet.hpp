@@ -145,13 +145,8 @@ protected:
     unsigned long long* m_clk;   // clock probe of the latest wavenet_wg launch (wn::Params::clk), when switched on
     bool m_clkOn;
 
-    // streams and events of run_chunks / run_stream, made on first use and kept
-    hipStream_t m_poolStream[2] = {NULL, NULL};
+    // events of run_chunks / run_stream, made on first use and kept
     std::vector<hipEvent_t> m_poolEvents;
-    hipStream_t pooledStream(int i) {
-        if (!m_poolStream[i]) gpuErrChk(hipStreamCreate(&m_poolStream[i]));
-        return m_poolStream[i];
-    }
     hipEvent_t pooledEvent(size_t i) {
         while (m_poolEvents.size() <= i) {
             hipEvent_t ev;
@@ -307,6 +302,9 @@ protected:
         const double tStream = (wBytes / (OrgTimes::kStreamBytesPerClk * OrgTimes::kClockMHz) + OrgTimes::kStreamLayerUs * m_numLayers + OrgTimes::kHeadUs) * rounds;
         const int stages = chainStagesFor(m_numLayers, lpc), perLaunch = m_numCUs / stages;
         const int tpc = (tiles + perLaunch - 1) / perLaunch;
+        // several tiles per chain: measured where wavenet_wg cannot be real time (C4, R = 128); the shapes with a three-tile
+        // wavenet_wg have their throughput organisation in that (C3: 1.3 utterances per CU and us against the chain's 0.7)
+        if (tpc > 1 && WG3) return single;
         double tChain = OrgTimes::kChainHopUs * stages + OrgTimes::kChainLayerUs(R) * m_numLayers + OrgTimes::kHeadUs;
         if (tpc * OrgTimes::kChainUnitUs > tChain) tChain = tpc * OrgTimes::kChainUnitUs;
         // (the time model of wavenet_wg is its one-tile latency: with two or three tiles per workgroup, i.e. beyond one tile per CU, a
@@ -482,8 +480,6 @@ public:
     virtual ~nvWavenetInfer() {
         gpuErrChk(hipDeviceSynchronize());
         for (hipEvent_t ev : m_poolEvents) gpuErrChk(hipEventDestroy(ev));
-        for (int i = 0; i < 2; i++)
-            if (m_poolStream[i]) gpuErrChk(hipStreamDestroy(m_poolStream[i]));
         gpuErrChk(hipFree(m_wblob));
         gpuErrChk(hipFree(m_bias));
         gpuErrChk(hipFree(m_embedPrev));
@@ -731,8 +727,12 @@ public:
             pc.delivered = pooledEvent(2 * pieces.size() + 1);
             pieces.push_back(pc);
         }
-        // (streams and events are the engine's, made once: creating and destroying them per call cost 1.4 ms, 3 % of a four-chunk call)
-        hipStream_t genStream = stream ? stream : pooledStream(0), outStream = pooledStream(1);
+        // (the events are the engine's, made once.  The two streams are made per call and destroyed at its end: streams kept alive
+        //  in the engine take hardware queues away from the caller's own streams -- with them pooled, a launch on a caller's side
+        //  stream queued up behind a kernel of another of its streams: tests/..::test_chain_launch_that_cannot_become_resident..)
+        hipStream_t genStream = stream, outStream;
+        if (!genStream) gpuErrChk(hipStreamCreate(&genStream));
+        gpuErrChk(hipStreamCreate(&outStream));
         bool ok = true;
         for (size_t k = 0; k < pieces.size(); k++) {
             const Piece& pc = pieces[k];
@@ -752,6 +752,8 @@ public:
             gpuErrChk(hipEventSynchronize(pieces[k].delivered));
             consume(yOut, pieces[k].first, pieces[k].count);
         }
+        if (!stream) gpuErrChk(hipStreamDestroy(genStream));
+        gpuErrChk(hipStreamDestroy(outStream));
         return ok;
     }
     // col-major Wprev,Wcur 2RxR; Bh 2R; Wres RxR; Bres R; Wskip SxR; Bskip S (nv_wavenet.cuh:400-409)
@@ -1019,8 +1021,12 @@ public:
             pc.delivered = pooledEvent(2 * pieces.size() + 1);
             pieces.push_back(pc);
         }
-        // (streams and events are the engine's, made once: creating and destroying them per call cost 1.4 ms, 3 % of a four-chunk call)
-        hipStream_t genStream = stream ? stream : pooledStream(0), outStream = pooledStream(1);
+        // (the events are the engine's, made once.  The two streams are made per call and destroyed at its end: streams kept alive
+        //  in the engine take hardware queues away from the caller's own streams -- with them pooled, a launch on a caller's side
+        //  stream queued up behind a kernel of another of its streams: tests/..::test_chain_launch_that_cannot_become_resident..)
+        hipStream_t genStream = stream, outStream;
+        if (!genStream) gpuErrChk(hipStreamCreate(&genStream));
+        gpuErrChk(hipStreamCreate(&outStream));
 
         bool ok = true;
         for (size_t k = 0; k < pieces.size(); k++) {
@@ -1041,6 +1047,8 @@ public:
             gpuErrChk(hipEventSynchronize(pieces[k].delivered));
             consume(yOut, pieces[k].first, pieces[k].count);
         }
+        if (!stream) gpuErrChk(hipStreamDestroy(genStream));
+        gpuErrChk(hipStreamDestroy(outStream));
         if (isChain() && chainStatus() != 0) ok = false;   // (everything has completed: the check costs nothing)
         return ok;
     }

@@ -453,6 +453,9 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
         char* const ringMine = (char*)p.ring + (size_t)tile * ringTile;
         // every ring store of the previous unit has completed (and is visible to the whole workgroup:
         // one L1 per CU); also orders the reuse of the h images and of the bias table after the prologue
+        // (round 5, measured and dropped at C4 with 4-6 tiles per chain: draining one unit later, in front of a unit's own ring stores:
+        //  no difference; requesting the next unit's conditioning and taps one unit ahead, behind the x hand-off -- the idle work is
+        //  2.6-4 us of a saturated stage's 8 us per unit -- needs 48 more registers: 24 spilled, 27.3 -> 19.7 kHz at 1024 utterances)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wg_barrier();
         WN_CT_DECL

@@ -28,7 +28,7 @@
 #define WN_REQ_AT 6          // wavenet_wg: eighths of the skip GEMM behind which taps and conditioning of layer l+2 are requested
 #endif
 #ifndef WN_REQ_AT_FEAT
-#define WN_REQ_AT_FEAT 4     // ... of the kernels that compute the conditioning: eighths of the (skip + conditioning) fragments under the gate
+#define WN_REQ_AT_FEAT 6     // ... of the kernels that compute the conditioning: eighths of the (skip + conditioning) fragments under the gate (4: +0.7 %)
 #endif
 // cache-policy bits of the buffer instructions (0 = default, 2 = nt / streaming, 16 = sc1)
 #ifndef WN_W_AUX

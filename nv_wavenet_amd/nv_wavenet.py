@@ -130,18 +130,11 @@ def cond_fragment_order(R, precision=16):
     return perm, scale
 
 
-def _fragments_from_ordered(x, tiles, dtype, out=None):
+def _fragments_from_ordered(x, tiles, dtype):
     """x [N][L][B][2R] with the channels already in fragment order (and pre-scaled) -> the engine's packed tensor
-    [N + 1][L][tiles][wave][fragment][g][j][EPL] (one zero padding sample, utterances padded to whole tiles).
-    out: N samples of an existing packed tensor ([N][L][tiles][wave*fragment][g][j][EPL], e.g. a slice of the buffer handed to
-    setConditioningPacked) to write into instead: the permuting copy lands there directly (a producer that streams the
-    conditioning chunk by chunk into one long buffer)."""
+    [N + 1][L][tiles][wave][fragment][g][j][EPL] (one zero padding sample, utterances padded to whole tiles)."""
     N, L, B, C2 = x.shape
     EPL = 8 if dtype == torch.float16 else 4
-    if out is not None:
-        assert B == tiles * 16, "writing into a packed buffer needs whole tiles (pad the batch)"
-        out.copy_(x.view(N, L, tiles, 16, C2 // (4 * EPL), 4, EPL).permute(0, 1, 2, 4, 5, 3, 6))
-        return out
     buf = torch.zeros(N + 1, L, tiles * 16, C2, dtype=dtype, device=x.device)
     buf[:N, :, :B] = x.to(dtype)
     buf = buf.view(N + 1, L, tiles, 16, C2 // (4 * EPL), 4, EPL)          # [n][l][tile][j][wave*fragment][g][e]
@@ -186,6 +179,21 @@ def cond_producer_weights(cond_weight, cond_bias, n_layers, precision=16):
     wg = w[:, rows.reshape(-1), :].reshape(n_layers, NWF, 2, 16, KF, 4, 8)                                     # [l][wf][tt][i][kf][ga][e]
     wfrag = wg.permute(0, 1, 2, 4, 5, 3, 6).contiguous().to(torch.float16)                                     # [l][wf][tt][kf][ga][i][e]
     return wfrag.reshape(n_layers, NWF, 2, KF, 64, 8), b, KF, NWF
+
+
+_producer_cache = {}
+
+
+def cond_producer_weights_cached(cond_weight, cond_bias, n_layers, precision=16):
+    """cond_producer_weights, kept per weight tensor (storage + version): a streaming caller produces the conditioning once per
+    chunk, and re-arranging the whole convolution weight every time cost as much as the producer kernel's own launch."""
+    key = (cond_weight.data_ptr(), cond_weight._version, cond_bias.data_ptr(), cond_bias._version, n_layers, precision, tuple(cond_weight.shape))
+    hit = _producer_cache.get(key)
+    if hit is None:
+        if len(_producer_cache) >= 4:
+            _producer_cache.pop(next(iter(_producer_cache)))
+        hit = _producer_cache[key] = cond_producer_weights(cond_weight, cond_bias, n_layers, precision)
+    return hit
 
 
 def produce_cond_packed(x_channels_last, wfrag, bias, out, tiles):
@@ -291,7 +299,8 @@ def get_cond_input(features, upsample_weight, upsample_bias, upsample_stride, co
         # the engine's own producer: upsampling as one matrix product (small), then the conditioning convolution by an MFMA kernel
         # that writes fragment order directly (csrc/cond_producer.hip)
         assert can_fuse, "fused=True needs layout='packed', out=, fp16 features on the GPU and a kernel that is a multiple of the stride"
-        wfrag, bpos, KF, _ = cond_producer_weights(cond_weight, cond_bias, n_layers, precision)
+        assert tiles is not None, "layout='packed' needs the engine's condTiles()"
+        wfrag, bpos, KF, _ = cond_producer_weights_cached(cond_weight, cond_bias, n_layers, precision)
         xcl = _upsample_trimmed_gemm(features, upsample_weight, upsample_bias, upsample_stride, pad_to=32)   # [B][N][32 KF]
         assert xcl.size(0) == tiles * 16, "writing into a packed buffer needs whole tiles (pad the batch)"
         return produce_cond_packed(xcl, wfrag, bpos, out, tiles)
