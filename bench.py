@@ -330,7 +330,7 @@ def end_to_end_khz(w, B, chunk=256, chunks=4, seed=21):
 UP_STRIDE, UP_WINDOW = 256, 1024             # upsampling of the synthetic model (the reference's is 200 / 800: the same four taps)
 
 
-def features_in_khz(w, B, chunk=256, chunks=4, seed=41):
+def features_in_khz(w, B, chunk=256, chunks=8, seed=41):
     """The deployable loop of round 5: FEATURES IN, SAMPLES OUT through one C-ABI call (nvw_generate_stream).  The engine holds the
     model's `upsample` and `cond_layers` (pytorch/wavenet.py:70-74); per chunk of `chunk` samples it upsamples the mel-like frames
     [B][80][frames] (fp16) with its own MFMA kernel into feature fragments, runs the generation launch -- which computes the
@@ -753,7 +753,7 @@ def main():
                              "HBM; per chunk of 256 samples the engine upsamples them with its own MFMA kernel (ConvTranspose1d, window 1024 / "
                              "stride 256) into 160 B of features per utterance and sample, and the generation launch computes the conditioning "
                              "Lh = Wcond c + bcond itself (wn::wavenet_wg<.., RAW=3>); samples copied out per chunk on a second stream; wall "
-                             "clock around the call, 4 chunks from sample 0", "sweep_khz": {}}
+                             "clock around the call, 8 chunks from sample 0", "sweep_khz": {}}
         best_fin = None
         for cand in sorted(set([B + 16 * ncu // 4, B, B - 16 * ncu // 4, B - 16 * ncu // 2, B * 3 // 4, B // 2]), reverse=True):
             cand = max(16, cand // 64 * 64)

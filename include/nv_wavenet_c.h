@@ -153,7 +153,7 @@ int nvw_set_features(nvw_engine* e, const void* x, int precision, long long b_st
  * WaveNet.get_cond_input -- the `upsample` ConvTranspose1d and the trimming of its tail, pytorch/wavenet.py:195-197 -- on the engine's
  * own MFMA kernel, writing the feature fragments the generation kernel reads:
  *   nvw_set_upsampling      upsample.weight [n_cond][n_cond][window] and .bias [n_cond] (fp32, host or device, copied); window a multiple
- *                           of stride, at most 8 strides (the reference: 800 / 200); after nvw_set_conditioning_weights
+ *                           of stride, at most 5 strides (the reference: 800 / 200); after nvw_set_conditioning_weights
  *   nvw_set_mel             the utterances' frames before upsampling, device tensor of 16- or 32-bit floats addressed
  *                           x[b*b_stride + c*c_stride + f*f_stride] ([B][n_cond][frames]: strides n_cond*frames, frames, 1); copied;
  *                           frames * stride <= the engine's samples; resets the history like nvw_set_inputs (start of a batch)

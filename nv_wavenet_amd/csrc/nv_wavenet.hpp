@@ -628,8 +628,8 @@ public:
     bool conditioningFromFeatures() const { return m_featPtr != NULL; }
     // ---- ... and the upsampling in front of it (the other half of WaveNet.get_cond_input, pytorch/wavenet.py:195-197) -----------
     // The model's `upsample` ConvTranspose1d: upW [nCond][nCond][window], upB [nCond], fp32, host or device, copied; window must be a
-    // multiple of stride (the reference's 800 / 200), at most 8 strides.  Needs setConditioningWeights first (the channel count).
-    static constexpr int kUpMaxTaps = 8;
+    // multiple of stride (the reference's 800 / 200), at most 5 strides.  Needs setConditioningWeights first (the channel count).
+    static constexpr int kUpMaxTaps = 5;      // (the operands of a workgroup's phases sit in LDS: phases x 5 x taps x KFC KiB <= 160 KiB)
     bool setUpsampling(const float* upW, const float* upB, int window, int stride) {
         if (m_nCond <= 0 || stride <= 0 || window < stride || window % stride != 0 || window / stride > kUpMaxTaps) return false;
         const size_t nW = (size_t)m_nCond * m_nCond * window;
@@ -690,14 +690,15 @@ public:
         m_featPtr = m_feat;
         m_featSamples = m_melFrames * m_upStride;
         const int m = m_upWindow / m_upStride, tilesUsed = (m_maxBatch + 15) / 16;
-        const size_t lds = (size_t)wn::kUpRowTiles * m * KFC * 1024;
+        const size_t lds = (size_t)wn::up_phases<F16>() * wn::kUpRowTiles * m * KFC * 1024;      // (a pair of phases in fp16)
         static bool allowed = false;
         if (!allowed) {
             gpuErrChk(hipFuncSetAttribute((const void*)wn::upsample_features_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             allowed = true;
         }
         // a phase per workgroup; phases with few columns (long strides, short chunks) get more workgroups per phase
-        const int gx = m_upStride < 1024 ? m_upStride : 1024;
+        const int pairs = (m_upStride + wn::up_phases<F16>() - 1) / wn::up_phases<F16>();
+        const int gx = pairs < 1024 ? pairs : 1024;
         const long long cols = (long long)((count + m_upStride - 1) / m_upStride + 1) * tilesUsed;
         int gy = (int)((cols + 255) / 256);         // (a wave takes groups of four columns)
         const int gyMax = (1024 + gx - 1) / gx;

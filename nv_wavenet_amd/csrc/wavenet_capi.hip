@@ -167,7 +167,7 @@ int nvw_pack_features(nvw_engine* e, const void* x, int precision, long long b_s
 }
 int nvw_set_upsampling(nvw_engine* e, const float* up_w, const float* up_b, int window, int stride) {
     if (!e->setUpsampling(up_w, up_b, window, stride)) {
-        fprintf(stderr, "nvw_set_upsampling: window %d / stride %d (a multiple of the stride, at most 8 strides; nvw_set_conditioning_weights first)\n",
+        fprintf(stderr, "nvw_set_upsampling: window %d / stride %d (a multiple of the stride, at most 5 strides; nvw_set_conditioning_weights first)\n",
                 window, stride);
         return 0;
     }

@@ -1923,6 +1923,9 @@ __global__ __launch_bounds__(256) void pack_features_kernel(typename Prec<F16>::
 // ARE feature fragments once converted to T_data.  A workgroup takes a phase: its operand A_r (RTU x m*KFC fragments) sits in LDS,
 // its four waves share the columns.
 constexpr int kUpRowTiles = (kCondChannelsMax + 15) / 16;
+// phases a workgroup of upsample_features_kernel takes at a time.  Two (fp16: the operands of both in LDS, a mel fragment feeding both)
+// were measured slower than one -- 120 KiB of LDS leave one workgroup per CU: 0.43 against 0.33 ms per chunk of 256 x 12 288
+template <bool F16> constexpr int up_phases() { return 1; }
 // table of the A operands: [stride][kUpRowTiles][m * KFC][64 lanes][EPL] from the ConvTranspose1d weight [n_cond][n_cond][window]
 template <bool F16>
 __global__ void pack_upsample_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ upW, int nCond, int window, int stride) {
@@ -1949,24 +1952,30 @@ __global__ __launch_bounds__(256) void upsample_features_kernel(typename Prec<F1
     using P = Prec<F16>;
     using frag = typename P::frag;
     constexpr int KFC = feat_kfc<F16>(), EPL = P::EPL, RTU = kUpRowTiles;
+    // A workgroup takes PB phases (their operands side by side in LDS: PB x RTU x m*KFC KiB) and a wave CB columns at a time: a mel
+    // fragment loaded from L2 feeds all PB phases, an operand fragment read from LDS feeds CB columns.  (One phase and one column per
+    // pass: bound by the LDS, 0.40 ms per chunk of 256 samples x 12 288 utterances; one phase, four columns: 0.33 ms, what ships.)
+    constexpr int CB = 4, PB = up_phases<F16>();
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4;
     const int nA = RTU * m * KFC;                                     // fragments of one phase's operand
-    for (int r = blockIdx.x; r < stride; r += gridDim.x) {
-        __syncthreads();                                              // (the previous phase's readers are done)
-        const uintx4* src = (const uintx4*)(tab + (size_t)r * nA * 64 * EPL);
-        for (int i = tid; i < nA * 64; i += 256) ((uintx4*)lds)[i] = src[i];
+    const int npair = (stride + PB - 1) / PB;
+    for (int pp = blockIdx.x; pp < npair; pp += gridDim.x) {
+        const int r0 = pp * PB;
+        __syncthreads();                                              // (the previous pair's readers are done)
+        for (int ph = 0; ph < PB; ph++) {
+            if (r0 + ph >= stride) break;
+            const uintx4* src = (const uintx4*)(tab + (size_t)(r0 + ph) * nA * 64 * EPL);
+            for (int i = tid; i < nA * 64; i += 256) ((uintx4*)lds)[(size_t)ph * nA * 64 + i] = src[i];
+        }
         __syncthreads();
-        // frames whose sample f*stride + r lies in [firstSample, firstSample + count)
-        int fLo = (firstSample - r + stride - 1) / stride;
+        // frames f with a sample f*stride + r, r in the pair, inside [firstSample, firstSample + count)
+        int fLo = (firstSample - (r0 + PB - 1) + stride - 1) / stride;
         if (fLo < 0) fLo = 0;
-        const int last = firstSample + count - 1 - r;
+        const int last = firstSample + count - 1 - r0;
         if (last < 0) continue;
         const int fHi = last / stride;
         const int ncol = (fHi - fLo + 1) * tilesUsed;
-        // CB columns per pass over the operand: an A fragment read from LDS feeds CB MFMAs (one column per pass is bound by the LDS:
-        // 60 KiB of operand reads per column, 0.40 ms per chunk of 256 samples x 12 288 utterances; four: 0.1 ms)
-        constexpr int CB = 4;
         const int ngrp = (ncol + CB - 1) / CB;
         for (int grp = blockIdx.y * 4 + w; grp < ngrp; grp += gridDim.y * 4) {
             int fcol[CB], tcol[CB];
@@ -1976,11 +1985,13 @@ __global__ __launch_bounds__(256) void upsample_features_kernel(typename Prec<F1
                 fcol[c] = fLo + col / tilesUsed;
                 tcol[c] = col % tilesUsed;
             }
-            floatx4 acc[CB][RTU];
+            floatx4 acc[PB][CB][RTU];
 #pragma unroll
-            for (int c = 0; c < CB; c++)
+            for (int ph = 0; ph < PB; ph++)
 #pragma unroll
-                for (int tr = 0; tr < RTU; tr++) acc[c][tr] = *(const floatx4*)(bias + tr * 16 + g * 4);
+                for (int c = 0; c < CB; c++)
+#pragma unroll
+                    for (int tr = 0; tr < RTU; tr++) acc[ph][c][tr] = *(const floatx4*)(bias + tr * 16 + g * 4);
             for (int j = 0; j < m; j++) {
                 frag b[CB][KFC];
 #pragma unroll
@@ -1997,31 +2008,36 @@ __global__ __launch_bounds__(256) void upsample_features_kernel(typename Prec<F1
                     }
                 }
 #pragma unroll
-                for (int kf = 0; kf < KFC; kf++)
+                for (int ph = 0; ph < PB; ph++)
 #pragma unroll
-                    for (int tr = 0; tr < RTU; tr++) {
-                        const frag a = *(const frag*)(lds + ((size_t)((tr * m + j) * KFC + kf) * 64 + lane) * 16);
+                    for (int kf = 0; kf < KFC; kf++)
 #pragma unroll
-                        for (int c = 0; c < CB; c++) acc[c][tr] = mma(a, b[c][kf], acc[c][tr]);
-                    }
+                        for (int tr = 0; tr < RTU; tr++) {
+                            const frag a = *(const frag*)(lds + ((size_t)ph * nA + (size_t)((tr * m + j) * KFC + kf)) * 1024 + (size_t)lane * 16);
+#pragma unroll
+                            for (int c = 0; c < CB; c++) acc[ph][c][tr] = mma(a, b[c][kf], acc[ph][c][tr]);
+                        }
             }
 #pragma unroll
-            for (int c = 0; c < CB; c++) {
-                if (grp * CB + c >= ncol) continue;
-                typename P::elem* out = feat + ((size_t)(fcol[c] * stride + r) * tiles + tcol[c]) * KFC * 64 * EPL;
+            for (int ph = 0; ph < PB; ph++)
 #pragma unroll
-                for (int kf = 0; kf < KFC; kf++) {
-                    frag o;
-                    if constexpr (F16) {
-                        const floatx4 lo = acc[c][2 * kf], hi = (2 * kf + 1 < RTU) ? acc[c][2 * kf + 1 < RTU ? 2 * kf + 1 : 0] : floatx4{0.f, 0.f, 0.f, 0.f};
-                        o = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2],
-                                  (_Float16)hi[3]};
-                    } else {
-                        o = acc[c][kf < RTU ? kf : 0];
+                for (int c = 0; c < CB; c++) {
+                    const int t = fcol[c] * stride + r0 + ph;
+                    if (grp * CB + c >= ncol || r0 + ph >= stride || t < firstSample || t >= firstSample + count) continue;
+                    typename P::elem* out = feat + ((size_t)t * tiles + tcol[c]) * KFC * 64 * EPL;
+#pragma unroll
+                    for (int kf = 0; kf < KFC; kf++) {
+                        frag o;
+                        if constexpr (F16) {
+                            const floatx4 lo = acc[ph][c][2 * kf], hi = (2 * kf + 1 < RTU) ? acc[ph][c][2 * kf + 1 < RTU ? 2 * kf + 1 : 0] : floatx4{0.f, 0.f, 0.f, 0.f};
+                            o = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2],
+                                      (_Float16)hi[3]};
+                        } else {
+                            o = acc[ph][c][kf < RTU ? kf : 0];
+                        }
+                        *(frag*)((char*)out + ((size_t)kf * 64 + lane) * 16) = o;
                     }
-                    *(frag*)((char*)out + ((size_t)kf * 64 + lane) * 16) = o;
                 }
-            }
         }
     }
 }
