@@ -193,7 +193,7 @@ if have("prof5c_kt"):
 if have("prof5d_kt"):
     doc = load("prof5d_kt")
     line = json.load(open(f"{G}/prof5d_line.json"))
-    name, k = kernel_of(doc, "wavenet_chainI")
+    name, k = kernel_of(doc, "ELb0EEEvNS_6ParamsENS_11ChainParamsE")      # (the dump-free variant; the harness warms up with the dumping one)
     FLOP4 = 7143424
     with open(f"{P}/r05_chain_c4_tiles_per_chain.txt", "w") as f:
         f.write("# round 5: python scripts/gpu_r5_chain.py C4 4  under  rocprofv3 --kernel-trace --stats (+ PMC passes in their own runs)\n")
@@ -208,12 +208,14 @@ if have("prof5d_kt"):
         c = {}
         for dd in ("fetch", "write", "issue"):
             if have(f"prof5d_{dd}"):
-                c.update(pmc_of(load(f"prof5d_{dd}"), "wavenet_chainI"))
+                c.update(pmc_of(load(f"prof5d_{dd}"), "ELb0EEEvNS_6ParamsENS_11ChainParamsE"))
         if "FETCH_SIZE" in c:
             tot_us = sum(1024 * n for n in (64, line["samples"] // 2, line["samples"] // 2, 640, 2048))      # utterance-samples of the script's chain launches
             f.write("# HBM over all chain launches of the run (%d utterance-samples): read %.0f B, written %.0f B per utterance-sample\n" %
                     (tot_us, 2 * c["FETCH_SIZE"] * 1024 / tot_us, c["WRITE_SIZE"] * 1024 / tot_us))
-            f.write("#   (algorithmic: conditioning 15 360 + dilated taps 7 680 read, ring 7 680 written; the hand-off granules are L2 traffic)\n")
+            f.write("#   (algorithmic: conditioning 15 360 + dilated taps 7 680 read, ring 7 680 written.  The rest is the hand-off: 8-byte granules,\n"
+                    "#    1 KiB of x per utterance and stage + 2 KiB of skip sums = 46 KB per utterance-sample over 15 + 16 hops, stored with\n"
+                    "#    relaxed atomics that are written through to memory, and the consumers' sweeps that miss L2 -- 0.1 TB/s at this rate)\n")
         issue_lines(c, f)
         for kk in sorted(c):
             f.write("%-32s %20.0f\n" % (kk, c[kk]))

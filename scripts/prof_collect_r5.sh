@@ -32,7 +32,7 @@ C)
   run prof5c_kt --kernel-trace --stats
   run prof5c_fetch --kernel-trace --pmc FETCH_SIZE
   run prof5c_write --kernel-trace --pmc WRITE_SIZE
-  grep -v amdgpu.ids gpurun_out/prof5c_kt.log | tail -8 > gpurun_out/prof5c_stdout.txt ;;
+  grep -E "^(upsampling|generation|nvw_)" gpurun_out/prof5c_kt.log > gpurun_out/prof5c_stdout.txt ;;
 D)
   CMD="python scripts/gpu_r5_chain.py C4 4"
   run prof5d_kt --kernel-trace --stats
