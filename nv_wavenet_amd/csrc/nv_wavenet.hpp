@@ -728,12 +728,16 @@ public:
             pc.delivered = pooledEvent(2 * pieces.size() + 1);
             pieces.push_back(pc);
         }
-        // (the events are the engine's, made once.  The two streams are made per call and destroyed at its end: streams kept alive
-        //  in the engine take hardware queues away from the caller's own streams -- with them pooled, a launch on a caller's side
-        //  stream queued up behind a kernel of another of its streams: tests/..::test_chain_launch_that_cannot_become_resident..)
-        hipStream_t genStream = stream, outStream;
-        if (!genStream) gpuErrChk(hipStreamCreate(&genStream));
-        gpuErrChk(hipStreamCreate(&outStream));
+        // (the events are the engine's, made once.  A second stream exists only where it buys something: when the samples or the PCM
+        //  go to HOST memory, so that the copy of a chunk overlaps the generation of the next; device-resident outputs are copied in
+        //  stream order, 20 us per chunk.  Made per call and destroyed at its end -- 1.4 ms -- because streams kept alive in the engine
+        //  take hardware queues away from the caller's own streams: with them pooled, a launch on a caller's side stream queued up
+        //  behind a kernel of another of its streams, tests/..::test_chain_launch_that_cannot_become_resident..)
+        const bool hostOut = (yOut != NULL && !isDevicePtr(yOut)) || (m_pcmUser != NULL && !isDevicePtr(m_pcmUser));
+        hipStream_t genStream = stream, outStream = stream;
+        const bool ownGen = hostOut && !stream;
+        if (ownGen) gpuErrChk(hipStreamCreate(&genStream));
+        if (hostOut) gpuErrChk(hipStreamCreate(&outStream));
         bool ok = true;
         for (size_t k = 0; k < pieces.size(); k++) {
             const Piece& pc = pieces[k];
@@ -743,7 +747,7 @@ public:
             m_num_samples_per_chunk = pc.count;
             ok = run_partial(pc.first, num_samples, batch_size, NULL, 1, false, genStream) && ok;
             gpuErrChk(hipEventRecord(pc.generated, genStream));
-            gpuErrChk(hipStreamWaitEvent(outStream, pc.generated, 0));
+            if (hostOut) gpuErrChk(hipStreamWaitEvent(outStream, pc.generated, 0));
             if (yOut) getYOut(yOut, pc.first, pc.count, outStream);
             if (m_pcmUser) getAudioOut(m_pcmUser, pc.first, pc.count, outStream);
             gpuErrChk(hipEventRecord(pc.delivered, outStream));
@@ -753,8 +757,8 @@ public:
             gpuErrChk(hipEventSynchronize(pieces[k].delivered));
             consume(yOut, pieces[k].first, pieces[k].count);
         }
-        if (!stream) gpuErrChk(hipStreamDestroy(genStream));
-        gpuErrChk(hipStreamDestroy(outStream));
+        if (ownGen) gpuErrChk(hipStreamDestroy(genStream));
+        if (hostOut) gpuErrChk(hipStreamDestroy(outStream));
         return ok;
     }
     // col-major Wprev,Wcur 2RxR; Bh 2R; Wres RxR; Bres R; Wskip SxR; Bskip S (nv_wavenet.cuh:400-409)
@@ -1022,12 +1026,16 @@ public:
             pc.delivered = pooledEvent(2 * pieces.size() + 1);
             pieces.push_back(pc);
         }
-        // (the events are the engine's, made once.  The two streams are made per call and destroyed at its end: streams kept alive
-        //  in the engine take hardware queues away from the caller's own streams -- with them pooled, a launch on a caller's side
-        //  stream queued up behind a kernel of another of its streams: tests/..::test_chain_launch_that_cannot_become_resident..)
-        hipStream_t genStream = stream, outStream;
-        if (!genStream) gpuErrChk(hipStreamCreate(&genStream));
-        gpuErrChk(hipStreamCreate(&outStream));
+        // (the events are the engine's, made once.  A second stream exists only where it buys something: when the samples or the PCM
+        //  go to HOST memory, so that the copy of a chunk overlaps the generation of the next; device-resident outputs are copied in
+        //  stream order, 20 us per chunk.  Made per call and destroyed at its end -- 1.4 ms -- because streams kept alive in the engine
+        //  take hardware queues away from the caller's own streams: with them pooled, a launch on a caller's side stream queued up
+        //  behind a kernel of another of its streams, tests/..::test_chain_launch_that_cannot_become_resident..)
+        const bool hostOut = (yOut != NULL && !isDevicePtr(yOut)) || (m_pcmUser != NULL && !isDevicePtr(m_pcmUser));
+        hipStream_t genStream = stream, outStream = stream;
+        const bool ownGen = hostOut && !stream;
+        if (ownGen) gpuErrChk(hipStreamCreate(&genStream));
+        if (hostOut) gpuErrChk(hipStreamCreate(&outStream));
 
         bool ok = true;
         for (size_t k = 0; k < pieces.size(); k++) {
@@ -1038,7 +1046,7 @@ public:
             // the last chunk runs the dump-capable kernel variant.
             ok = run_partial(pc.first, num_samples, batch_size, NULL, batch_size_per_block, k + 1 == pieces.size(), genStream) && ok;
             gpuErrChk(hipEventRecord(pc.generated, genStream));
-            gpuErrChk(hipStreamWaitEvent(outStream, pc.generated, 0));
+            if (hostOut) gpuErrChk(hipStreamWaitEvent(outStream, pc.generated, 0));
             if (yOut) getYOut(yOut, pc.first, pc.count, outStream);
             if (m_pcmUser) getAudioOut(m_pcmUser, pc.first, pc.count, outStream);
             gpuErrChk(hipEventRecord(pc.delivered, outStream));
@@ -1048,8 +1056,8 @@ public:
             gpuErrChk(hipEventSynchronize(pieces[k].delivered));
             consume(yOut, pieces[k].first, pieces[k].count);
         }
-        if (!stream) gpuErrChk(hipStreamDestroy(genStream));
-        gpuErrChk(hipStreamDestroy(outStream));
+        if (ownGen) gpuErrChk(hipStreamDestroy(genStream));
+        if (hostOut) gpuErrChk(hipStreamDestroy(outStream));
         if (isChain() && chainStatus() != 0) ok = false;   // (everything has completed: the check costs nothing)
         return ok;
     }
