@@ -30,6 +30,14 @@ def shard_inputs(Lh, sel, world_size, rank):
     return Lh[:, :, s:s + n].contiguous(), sel[:, s:s + n].contiguous()
 
 
+def shard_features(x, world_size, rank):
+    """The same for the conditioning's SOURCE (round 5: the conditioning is computed in the generation kernel): mel frames or upsampled
+    features [B][n_cond][frames | samples] are batch-major, so a rank's share is a contiguous row range -- no copy for torch tensors
+    (a view; WavenetEngine.setMel / setFeatures take any strides), a contiguous slice for numpy arrays."""
+    s, n = shard_range(x.shape[0], world_size, rank)
+    return np.ascontiguousarray(x[s:s + n]) if isinstance(x, np.ndarray) else x[s:s + n]
+
+
 def gather_samples(y_local, total_batch, group=None, async_op=False):
     """All ranks contribute their [b_local][N] int32 block; every rank receives the [B][N] result
     (one all_gather over RCCL/xGMI: 4*B*N bytes in total). Ragged shards are padded to the

@@ -25,6 +25,32 @@ def test_shard_range_is_a_partition():
             assert max(n for _, n in spans) - min(n for _, n in spans) <= 1
 
 
+def test_feature_shards_give_the_conditioning_of_the_batch_shard():
+    """Round 5: with the conditioning computed in the kernel a rank is handed its rows of the features instead of its slice of Lh:
+    Wcond x_shard + bcond must be the shard of Wcond x + bcond."""
+    import cases
+    import condgen
+    from nv_wavenet_amd.sharding import shard_features, shard_inputs, shard_range
+    cc = condgen.COND_BY_NAME["cond_oddL_B19"]
+    s = cases.BY_NAME[cc.case_name].shape
+    m = condgen.make_cond_model(cc, s)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((s.B, cc.n_cond, s.N)).astype(np.float32)
+    w = m["cond_w"][:, :, 0]
+    lh = (np.einsum("oc,bct->bot", w, x) + m["cond_b"][None, :, None]).reshape(s.B, s.L, 2 * s.R, s.N).transpose(3, 1, 0, 2)   # [N][L][B][2R]
+    sel = rng.random((s.N, s.B), dtype=np.float32)
+    for world in (2, 3, 8):
+        for rank in range(world):
+            xs = shard_features(x, world, rank)
+            start, n = shard_range(s.B, world, rank)
+            assert xs.shape == (n, cc.n_cond, s.N) and np.array_equal(xs, x[start:start + n])
+            lh_r, _ = shard_inputs(np.ascontiguousarray(lh), sel, world, rank)
+            mine = (np.einsum("oc,bct->bot", w, xs) + m["cond_b"][None, :, None]).reshape(n, s.L, 2 * s.R, s.N).transpose(3, 1, 0, 2)
+            assert np.array_equal(np.ascontiguousarray(mine), lh_r)
+            xt = shard_features(torch.from_numpy(x), world, rank)
+            assert xt.data_ptr() == torch.from_numpy(x)[start:start + n].data_ptr() if n else True      # (a view, no copy)
+
+
 def _worker(rank, world, port, total_batch, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
