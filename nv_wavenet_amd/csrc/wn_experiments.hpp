@@ -50,12 +50,12 @@
 #define WN_FEAT_AUX 0        // upsampled features (in-kernel conditioning): every wave of a workgroup reads the same fragments
 #endif
 
-// ---- ablations: TIMING ONLY -- the samples are wrong with any of them (none is defined in a product build) -------------------
-//   wavenet_wg   WN_ABL_NOACT          gate without transcendentals        WN_ABL_NOWEIGHTLOAD  no weight refills
-//                WN_ABL_NOXP           no dilated-tap loads                WN_ABL_NOCOND        no conditioning loads
-//                WN_ABL_HOTLOADS / WN_ABL_HOTTAPS / WN_ABL_HOTCOND         taps / conditioning always from the same, L2-resident rows
-//                WN_ABL_NOTAPGEMM      the tap GEMM's MFMAs not issued     WN_ABL_NOBARRIER     no workgroup barriers
-//                WN_ABL_NOHEADRES      no resident head matrix
+// ---- ablations --------------------------------------------------------------------------------------------------------------------
+// The timing-only builds of rounds 2-4 (WN_ABL_NOACT, _NOWEIGHTLOAD, _NOXP, _NOCOND, _HOTLOADS / _HOTTAPS / _HOTCOND, _NOTAPGEMM,
+// _NOBARRIER, _NOHEADRES: gate without transcendentals, no weight refills, no tap / conditioning loads or L2-resident ones, ...) were
+// taken out of wn_kernels.hpp in round 5: their measurements are in LABNOTES.md (rounds 2-4), their code in commit c19e716.  What they
+// were built to decide -- whether the full-chip launch is bound by its memory traffic -- was settled by removing the conditioning
+// stream for real (round 5).
 // ---- probes (results stay right) ------------------------------------------------------------------------------------------
 //   WN_TIMING        wavenet_wg: per-phase shader-clock sums of wave 0 into Params::p (scripts/quick_phase.py)
 //   WN_CHAIN_TIMING  wavenet_chain: wall-clock stamps per stage (scripts/chain_phase.py)

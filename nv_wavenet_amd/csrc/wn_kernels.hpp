@@ -155,16 +155,12 @@ struct Cfg {
     // the head then needs no weight stream at all (it is purely stream-bound otherwise).
     // HR = number of resident fragments (the tail of the head: all of it, or the A x A matrix only
     // when registers are scarcer, e.g. two tiles per workgroup); HS = head fragments still streamed.
-#ifdef WN_ABL_NOHEADRES
-    static constexpr int HR = 0;
-#else
     // Register budget of the resident head.  Measured (C3 fp16): keeping Wzs resident as well (256
     // registers) buys nothing over Wza alone (128) and costs spills once the layer loop is unrolled.
     static constexpr int HR = !F16 ? 0
                               : BT == 1 ? (FW_ZA * 4 <= WN_HEADREGS ? FW_ZA : 0)
                               : BT == 2 ? (FW_ZA * 4 <= WN_HEADREGS2 ? FW_ZA : 0)
                                         : (FW_ZA * 4 <= WN_HEADREGS3 ? FW_ZA : 0);
-#endif
     static constexpr int HS = FHW - HR;
     static constexpr bool HEADRES = HS == 0;              // the stream cycles over the layers only
     // The head's part of a wave's stream is laid out  zs | PAD1 | za | PAD2  with zero fragments that bring each matrix
@@ -309,11 +305,7 @@ WN_DEV float philox_selector(unsigned k0, unsigned k1, unsigned t, unsigned b) {
 }
 
 // sigmoid: relative error of a few ulp (no cancellation)
-#ifndef WN_ABL_NOACT
 WN_DEV float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
-#else
-WN_DEV float sigmoid_f(float x) { return x; }
-#endif
 
 // tanh, fp16 engine: result is rounded to fp16 afterwards, 1 - 2/(e^2x+1) is ample.
 WN_DEV float tanh_fast(float x) {
@@ -337,11 +329,7 @@ WN_DEV float tanh_acc(float x) {
     big = __builtin_copysignf(big, x);
     return a < 0.55f ? small : big;
 }
-#ifndef WN_ABL_NOACT
 template <bool F16> WN_DEV float tanh_t(float x) { return F16 ? tanh_fast(x) : tanh_acc(x); }
-#else
-template <bool F16> WN_DEV float tanh_t(float x) { return x; }
-#endif
 
 // ---- the gate  h = tanh(a) * sigmoid(b) ---------------------------------------------------------
 // fp32 engine: the accurate scalar forms above (parity bars are relative, nv_wavenet_test.cu:273-298).
@@ -356,16 +344,11 @@ template <bool F16> __host__ __device__ constexpr float gate_prescale(bool sigmo
     return !F16 ? 1.0f : sigmoidRow ? -1.44269504088896340736f : 2.88539008177792681472f;
 }
 template <bool F16> WN_DEV float gate1(float a, float b);
-#ifdef WN_ABL_NOACT
-template <> WN_DEV float gate1<false>(float a, float b) { return a * b; }
-template <> WN_DEV float gate1<true>(float a, float b) { return a * b; }
-#else
 template <> WN_DEV float gate1<false>(float a, float b) { return tanh_acc(a) * sigmoid_f(b); }
 WN_DEV float gate_finish(float ra, float rb) { return (1.0f - 2.0f * ra) * rb; }
 template <> WN_DEV float gate1<true>(float a, float b) {
     return gate_finish(fast_rcp(__builtin_amdgcn_exp2f(a) + 1.0f), fast_rcp(1.0f + __builtin_amdgcn_exp2f(b)));
 }
-#endif
 // The same gate for a pair of values in five stages (exp2 a | exp2 b | rcp | rcp | product), so that wavenet_wg can
 // issue one MFMA of an independent GEMM between two stages: a lone wave issues about two VALU instructions in the
 // time one MFMA executes, and the gate is where a layer's VALU time is.  Same operations per value as gate1
@@ -374,9 +357,6 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 template <bool F16, int ST>
 WN_DEV void gate_stage(float a0, float a1, float b0, float b1, floatx2& ea, floatx2& eb, floatx2& ra, floatx2& rb,
                        floatx2& h) {
-#ifdef WN_ABL_NOACT
-    if constexpr (ST == 4) h = floatx2{a0 * b0, a1 * b1};
-#else
     if constexpr (!F16) {
         if constexpr (ST == 4) h = floatx2{gate1<false>(a0, b0), gate1<false>(a1, b1)};
     } else {
@@ -388,7 +368,6 @@ WN_DEV void gate_stage(float a0, float a1, float b0, float b1, floatx2& ea, floa
         if constexpr (ST == 3) rb = floatx2{fast_rcp(eb[0] + 1.0f), fast_rcp(eb[1] + 1.0f)};
         if constexpr (ST == 4) h = floatx2{gate_finish(ra[0], rb[0]), gate_finish(ra[1], rb[1])};
     }
-#endif
 }
 
 // compile-time loops: f(std::integral_constant<int, I>{}) for I in [0, N) / [A, B)
@@ -421,11 +400,7 @@ WN_DEV floatx4 quad_to_f32(floatx4 q) { return q; }
 // Workgroup barrier that does NOT wait for outstanding global loads (the weight prefetch ring
 // stays in flight across it): only this wave's LDS traffic is drained. __syncthreads() would emit
 // s_waitcnt vmcnt(0) as well.
-#ifndef WN_ABL_NOBARRIER
 WN_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#else
-WN_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#endif
 
 // ---- LDS exchange of activations as B fragments -------------------------------------------
 // tile t of a vector, held in MFMA D layout (fp32), goes to its place in the fragment image
@@ -483,7 +458,6 @@ WN_DEV typename Prec<F16>::frag take(WStream<F16, PF, PIN>& ws, int idx, const c
     using frag = typename Prec<F16>::frag;
     frag a = agpr_operand<F16 && PIN>(ws.buf[idx % PF]);   // the ring lives in the accumulator file (see agpr_pin)
     int nidx = idx + PF;
-#ifndef WN_ABL_NOWEIGHTLOAD
     // base / wrapBase are wave-uniform (SGPR base), laneOff = lane*16.  rtWrapAt/rtWrapDelta: a
     // run-time (uniform) wrap point, used when the stream cycles over the layers only.
     const char* src = (WRAP > 0 && nidx >= WRAP) ? wrapBase + (size_t)(nidx - WRAP) * 1024 : base + (size_t)nidx * 1024;
@@ -494,9 +468,6 @@ WN_DEV typename Prec<F16>::frag take(WStream<F16, PF, PIN>& ws, int idx, const c
     // youngest requests (a near-drain of the queue): pinned, C3 fp16 runs 39.0 instead of 42.0 us per
     // sample with two tiles per workgroup at batch 8192.
     __builtin_amdgcn_sched_barrier(0);
-#else
-    (void)nidx; (void)base; (void)wrapBase; (void)laneOff; (void)rtWrapAt; (void)rtWrapDelta;
-#endif
     return a;
 }
 
@@ -582,7 +553,6 @@ WN_DEV void take_group(WStream<F16, PF, PIN>& ws, int idx, typename Prec<F16>::f
 template <bool F16, int PF, int WRAP, bool PIN, int G>
 WN_DEV void refill_group(WStream<F16, PF, PIN>& ws, rsrc_t rs, int idx, int basePos, int wrapPos, unsigned laneOff) {
     using frag = typename Prec<F16>::frag;
-#ifndef WN_ABL_NOWEIGHTLOAD
 #pragma unroll
     for (int i = 0; i < G; i++) {
         const int nidx = idx + i + PF;
@@ -592,7 +562,6 @@ WN_DEV void refill_group(WStream<F16, PF, PIN>& ws, rsrc_t rs, int idx, int base
         ws.buf[(idx + i) % PF] = buf_load<frag, WN_W_AUX>(rs, laneOff + (unsigned)(rel & 3) * 1024u, (unsigned)pos * 1024u);
     }
     __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 // acc[bt][mt] += W(tile mt) * b[bt]   (fragment order as in gemm())
 // BPIN: the B operands live in the accumulator file as well (agpr_pin; the per-sample feature fragments of the in-kernel conditioning)
@@ -1014,19 +983,10 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     for (int bt = 0; bt < BT; bt++) rawOff[bt] = ((unsigned)ub[bt] * (unsigned)(2 * R) + (unsigned)g * 4u) * RAWE;
     auto prefetch = [&](int tn, int ln, Dil dl, frag (&xd)[BT][XPW], frag (&cdd)[BT][CR]) {
         if (ln >= L) { ln -= L; tn += 1; }
-        // timing experiments: taps (WN_ABL_HOTTAPS) and / or conditioning (WN_ABL_HOTCOND) always from the same, L2-resident
-        // addresses; WN_ABL_HOTLOADS = both
-#if defined(WN_ABL_HOTLOADS) || defined(WN_ABL_HOTTAPS)
-        const unsigned slot = (unsigned)(dl.off & 1);
-#else
         const unsigned slot = (unsigned)(dl.off + (tn & (dl.d - 1)));
-#endif
         const unsigned rp0 = slot * (unsigned)(KF_R * 1024);
         const rsrc_t rsCond = make_rsrc(condNext);
-#if !defined(WN_ABL_HOTLOADS) && !defined(WN_ABL_HOTCOND)
         condNext += condStride;
-#endif
-#ifndef WN_ABL_NOXP
 #pragma unroll
         for (int i = 0; i < XPW; i++) {
             const int k = w + NW * i;
@@ -1036,17 +996,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     xd[bt][i] = buf_load<frag, WN_RING_LD_AUX>(rsRing, laneOff, rp0 + (unsigned)bt * ringTileB + (unsigned)k * 1024u);
             }
         }
-#endif
 #pragma unroll
         for (int bt = 0; bt < BT; bt++) {
-#ifdef WN_ABL_NOXP
-            // timing experiment: a value the compiler cannot fold (keeps all downstream work alive)
-#pragma unroll
-            for (int i = 0; i < XPW; i++)
-#pragma unroll
-                for (int e = 0; e < P::EPL; e++) xd[bt][i][e] = (elem)(float)(tn + i);
-#endif
-#ifndef WN_ABL_NOCOND
             if constexpr (FEAT) {
                 // nothing to load per layer
             } else if constexpr (RAW != 0) {
@@ -1071,12 +1022,6 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     cdd[bt][k] = buf_load<frag, WN_COND_AUX>(rsCond, laneOff + (unsigned)(k & 3) * 1024u,
                                                    (unsigned)((bt * NW * C::COND_FR + (k & ~3)) * 1024));
             }
-#else
-#pragma unroll
-            for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                for (int e = 0; e < P::EPL; e++) cdd[bt][k][e] = (elem)(float)(ln + k) * (elem)0.001f;
-#endif
         }
     };
     prefetch(p.initSample, 0, p.dil[0], xpA, cdA);
@@ -1500,12 +1445,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(xbuf + bt * KF_R * 1024, lane, xb[bt]);
             __builtin_amdgcn_sched_barrier(0);
-#ifdef WN_ABL_NOTAPGEMM      // timing experiment: the tap GEMM's fragments taken (the ring keeps turning), its MFMAs not issued
-            skip_frags<F16, PF, 0, ws_pin, 4>(ws, rsW, C::P_PREV - PB, wl, 0, laneOff);
-            (void)xp;
-#else
             gemm_b<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, rsW, C::P_PREV - PB, wl, 0, laneOff, acc, xp);
-#endif
         };
         {
             // schedule entries of layers l, l+1, l+2 (the latter two may be layers 0, 1 of the next sample: table entries L, L+1)
