@@ -564,8 +564,7 @@ WN_DEV void refill_group(WStream<F16, PF, PIN>& ws, rsrc_t rs, int idx, int base
     __builtin_amdgcn_sched_barrier(0);
 }
 // acc[bt][mt] += W(tile mt) * b[bt]   (fragment order as in gemm())
-// BPIN: the B operands live in the accumulator file as well (agpr_pin; the per-sample feature fragments of the in-kernel conditioning)
-template <bool F16, int PF, int WRAP, int BT, int MT, int KF, bool PIN, bool BPIN = false>
+template <bool F16, int PF, int WRAP, int BT, int MT, int KF, bool PIN>
 WN_DEV void gemm_b(WStream<F16, PF, PIN>& ws, rsrc_t rs, int pos0, int basePos, int wrapPos, unsigned laneOff,
                    floatx4 (&acc)[BT][MT], const typename Prec<F16>::frag (&b)[BT][KF]) {
     constexpr int G = MT >= 4 ? 4 : MT;
@@ -589,7 +588,7 @@ WN_DEV void gemm_b(WStream<F16, PF, PIN>& ws, rsrc_t rs, int pos0, int basePos, 
                 for (int mi = 0; mi < TG; mi++)
 #pragma unroll
                     for (int bt = 0; bt < BT; bt++)
-                        acc[bt][mg * G + m0 + mi] = mma(a[mi], agpr_operand<BPIN>(b[bt][kf]), acc[bt][mg * G + m0 + mi]);
+                        acc[bt][mg * G + m0 + mi] = mma(a[mi], b[bt][kf], acc[bt][mg * G + m0 + mi]);
                 if (!EARLY || (mg == MT / G - 1 && kf == KF - 1 && m0 + TG >= G)) refill_group<F16, PF, WRAP, PIN, TG>(ws, rs, idx, basePos, wrapPos, laneOff);
             }
         }
