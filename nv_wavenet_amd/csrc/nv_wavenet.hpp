@@ -700,11 +700,11 @@ public:
         const int pairs = (m_upStride + wn::up_phases<F16>() - 1) / wn::up_phases<F16>();
         const int gx = pairs < 1024 ? pairs : 1024;
         const long long cols = (long long)((count + m_upStride - 1) / m_upStride + 1) * tilesUsed;
-        int gy = (int)((cols + 255) / 256);         // (a wave takes groups of four columns)
+        int gy = (int)((cols + 255) / 256);         // (a wave takes groups of two or four columns)
         const int gyMax = (1024 + gx - 1) / gx;
         if (gy > gyMax) gy = gyMax;
         if (gy < 1) gy = 1;
-        hipLaunchKernelGGL((wn::upsample_features_kernel<F16>), dim3(gx, gy), dim3(256), lds, stream, m_feat, m_melFrag, m_upTab, m_upBias, m, m_upStride,
+        hipLaunchKernelGGL((wn::upsample_features_kernel<F16>), dim3(gx, gy), dim3(64 * wn::up_waves<F16>()), lds, stream, m_feat, m_melFrag, m_upTab, m_upBias, m, m_upStride,
                            m_tiles, tilesUsed, firstSample, count);
         gpuErrChk(hipGetLastError());
     }

@@ -30,6 +30,9 @@
 #ifndef WN_REQ_AT_FEAT
 #define WN_REQ_AT_FEAT 6     // ... of the kernels that compute the conditioning: eighths of the (skip + conditioning) fragments under the gate (4: +0.7 %)
 #endif
+#ifndef WN_UP_PHASES
+#define WN_UP_PHASES(F16) 1     // upsample_features_kernel: phases per workgroup pass (2 = eight-wave workgroups, fp16 only; measured slower)
+#endif
 // cache-policy bits of the buffer instructions (0 = default, 2 = nt / streaming, 16 = sc1)
 #ifndef WN_W_AUX
 #define WN_W_AUX 0           // the weight stream: must stay in L2 (nt: +20 % per sample)

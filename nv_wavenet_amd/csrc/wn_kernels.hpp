@@ -1862,9 +1862,13 @@ __global__ __launch_bounds__(256) void pack_features_kernel(typename Prec<F16>::
 // ARE feature fragments once converted to T_data.  A workgroup takes a phase: its operand A_r (RTU x m*KFC fragments) sits in LDS,
 // its four waves share the columns.
 constexpr int kUpRowTiles = (kCondChannelsMax + 15) / 16;
-// phases a workgroup of upsample_features_kernel takes at a time.  Two (fp16: the operands of both in LDS, a mel fragment feeding both)
-// were measured slower than one -- 120 KiB of LDS leave one workgroup per CU: 0.43 against 0.33 ms per chunk of 256 x 12 288
-template <bool F16> constexpr int up_phases() { return 1; }
+// phases (PB) and columns (CB) a wave of upsample_features_kernel takes per pass, waves per workgroup.  One phase, four columns, four waves
+// ships: 0.32-0.33 ms per chunk of 256 samples x 12 288 utterances -- 0.60 GB of feature fragments written to HBM (its floor: ~0.15 ms) and
+// 2.4 GB of mel fragments read through L2.  Two phases' operands side by side in LDS (120 KiB at four taps, one workgroup per CU) halve
+// that L2 traffic and were measured slower both with four waves per workgroup (0.43 ms) and with eight (0.36-0.37 ms, same GPU call).
+template <bool F16> constexpr int up_phases() { return WN_UP_PHASES(F16); }
+template <bool F16> constexpr int up_cols() { return up_phases<F16>() > 1 ? 2 : 4; }
+template <bool F16> constexpr int up_waves() { return up_phases<F16>() > 1 ? 8 : 4; }
 // table of the A operands: [stride][kUpRowTiles][m * KFC][64 lanes][EPL] from the ConvTranspose1d weight [n_cond][n_cond][window]
 template <bool F16>
 __global__ void pack_upsample_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ upW, int nCond, int window, int stride) {
@@ -1885,7 +1889,7 @@ __global__ void pack_upsample_kernel(typename Prec<F16>::elem* __restrict__ dst,
     }
 }
 template <bool F16>
-__global__ __launch_bounds__(256) void upsample_features_kernel(typename Prec<F16>::elem* __restrict__ feat, const typename Prec<F16>::elem* __restrict__ melfrag,
+__global__ __launch_bounds__(64 * up_waves<F16>()) void upsample_features_kernel(typename Prec<F16>::elem* __restrict__ feat, const typename Prec<F16>::elem* __restrict__ melfrag,
                                                                 const typename Prec<F16>::elem* __restrict__ tab, const float* __restrict__ bias, int m,
                                                                 int stride, int tiles, int tilesUsed, int firstSample, int count) {
     using P = Prec<F16>;
@@ -1894,7 +1898,7 @@ __global__ __launch_bounds__(256) void upsample_features_kernel(typename Prec<F1
     // A workgroup takes PB phases (their operands side by side in LDS: PB x RTU x m*KFC KiB) and a wave CB columns at a time: a mel
     // fragment loaded from L2 feeds all PB phases, an operand fragment read from LDS feeds CB columns.  (One phase and one column per
     // pass: bound by the LDS, 0.40 ms per chunk of 256 samples x 12 288 utterances; one phase, four columns: 0.33 ms, what ships.)
-    constexpr int CB = 4, PB = up_phases<F16>();
+    constexpr int CB = up_cols<F16>(), PB = up_phases<F16>(), NWU = up_waves<F16>(), NTH = 64 * NWU;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4;
     const int nA = RTU * m * KFC;                                     // fragments of one phase's operand
@@ -1905,7 +1909,7 @@ __global__ __launch_bounds__(256) void upsample_features_kernel(typename Prec<F1
         for (int ph = 0; ph < PB; ph++) {
             if (r0 + ph >= stride) break;
             const uintx4* src = (const uintx4*)(tab + (size_t)(r0 + ph) * nA * 64 * EPL);
-            for (int i = tid; i < nA * 64; i += 256) ((uintx4*)lds)[(size_t)ph * nA * 64 + i] = src[i];
+            for (int i = tid; i < nA * 64; i += NTH) ((uintx4*)lds)[(size_t)ph * nA * 64 + i] = src[i];
         }
         __syncthreads();
         // frames f with a sample f*stride + r, r in the pair, inside [firstSample, firstSample + count)
@@ -1916,7 +1920,7 @@ __global__ __launch_bounds__(256) void upsample_features_kernel(typename Prec<F1
         const int fHi = last / stride;
         const int ncol = (fHi - fLo + 1) * tilesUsed;
         const int ngrp = (ncol + CB - 1) / CB;
-        for (int grp = blockIdx.y * 4 + w; grp < ngrp; grp += gridDim.y * 4) {
+        for (int grp = blockIdx.y * NWU + w; grp < ngrp; grp += gridDim.y * NWU) {
             int fcol[CB], tcol[CB];
 #pragma unroll
             for (int c = 0; c < CB; c++) {
