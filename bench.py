@@ -702,7 +702,7 @@ def main():
                         sweep_mc[str(shb.B)] = k
                         if k >= REALTIME_KHZ and "wavenet_chain" in info_k:
                             n_rd = 4096
-                            while n_rd > 512 and n_rd * shb.L * shb.B * 2 * shb.R * 4 > 64e9:      # (the harness hands over the whole fp32 tensor)
+                            while n_rd > 512 and n_rd * shb.L * shb.B * 2 * shb.R * 4 > 70e9:      # (the harness hands over the whole fp32 tensor)
                                 n_rd //= 2
                             r = reference_definition_khz(shb, 3, N=n_rd, chunk=n_rd // 2)
                             r["steady_state_khz_per_utterance"] = k

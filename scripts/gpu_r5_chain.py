@@ -21,7 +21,7 @@ def main():
         chains = ncu // stages
         B = 16 * chains * tpc
         N = 4096
-        while N > 512 and N * sh0.L * B * 2 * sh0.R * 4 > 64e9:      # (the harness hands over the whole fp32 conditioning tensor)
+        while N > 512 and N * sh0.L * B * 2 * sh0.R * 4 > 70e9:      # (the harness hands over the whole fp32 conditioning tensor)
             N //= 2
         sh = bench.Shape(sh0.name, sh0.R, sh0.S, sh0.A, sh0.L, sh0.maxD, B)
         r = bench.reference_definition_khz(sh, 3, N=N, chunk=N // 2)
