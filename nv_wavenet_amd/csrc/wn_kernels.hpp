@@ -939,9 +939,10 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     // conditioning registers per tile: COND_FR packed fragments, or (fp16, in-place) one fp32 quad per gate tile
     constexpr int CR = (RAW == 1 && F16) ? 2 * C::COND_FR : C::COND_FR;
     frag cdA[BT][CR], cdB[BT][CR];      // (unused when the conditioning is computed here: FEAT)
-    // FEAT: the feature fragments of the sample being generated (cfCur) and of the next one (cfNext): the conditioning GEMM at
-    // the end of the last layer belongs to layer 0 of the NEXT sample, so cfNext moves into cfCur behind the last-but-one
-    // layer's conditioning GEMM and is requested again (sample t+2) behind the layer loop -- a whole sample ahead of its use
+    // FEAT: the feature fragments of the sample being generated (cfCur) and of the next one (cfNext): the conditioning GEMM under
+    // the gate of the last layer belongs to layer 0 of the NEXT sample, so cfNext moves into cfCur behind the conditioning GEMM
+    // under the last-but-one layer's gate, and is requested again (sample t+2) behind the sample's last take -- a whole sample
+    // ahead of its use
     constexpr int KFCR = FEAT ? KFC : 1;
     frag cfCur[BT][KFCR], cfNext[BT][KFCR];
     const size_t featStride = (size_t)p.tiles * KFC * 1024;                          // one sample of features
@@ -1222,9 +1223,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             // gate -> h tiles of this wave -> LDS, in stages (pairs of values: exp2 a | exp2 b | rcp | rcp | product)
             // with the MFMAs of the previous layer's skip GEMM in between:  skip <- Wskip h + skip
             // FEAT: ... and behind them the conditioning GEMM of the NEXT layer, accN <- (Bh + bcond) + Wcond c, likewise MFMA by MFMA
-            // under the gate: the matrix core is idle there and nothing of it is on the dependent chain (at the end of the layer,
-            // where the packed conditioning is added, 6 k-steps per tile sit between the x stores and the x barrier: 540 clk per
-            // layer at three tiles, measured)
+            // under the gate: nothing of it is on the dependent chain there (at the end of the layer, where the packed
+            // conditioning is added, 6 k-steps per tile sit between the x stores and the x barrier: 540 clk per layer at three
+            // tiles, measured)
             floatx4 accN[FEAT ? BT : 1][2 * HTW];
             if constexpr (FEAT) {
 #pragma unroll
