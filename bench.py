@@ -707,6 +707,15 @@ def main():
                             r = reference_definition_khz(shb, 3, N=n_rd, chunk=n_rd // 2)
                             r["steady_state_khz_per_utterance"] = k
                             r["mfma_frac_of_dense_fp16_peak"] = shb.flops * shb.B * k * 1e3 / (MFMA_F16_PEAK_TFLOPS * 1e12)
+                            # the organisation's own roofline (steady state): algorithmic flops of the shape x utterance-samples per second
+                            # against the dense fp16 MFMA peak; what bounds it is the per-stage latency of the dependent chain, not a roof
+                            r["roofline"] = dict(bound="mfma", achieved=shb.flops * shb.B * k * 1e3 / 1e12, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
+                                                 frac=shb.flops * shb.B * k * 1e3 / (MFMA_F16_PEAK_TFLOPS * 1e12),
+                                                 hbm=dict(achieved=shb.B * k * 1e3 * (shb.hbm_bytes + 2 * 2 * shb.R * shb.L) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                                          bytes_per_utterance_sample=shb.hbm_bytes + 2 * 2 * shb.R * shb.L,
+                                                          note="conditioning + ring, algorithmic; the hand-off granules add 46 KB written per "
+                                                               "utterance-sample (profiles/r05_chain_c4_tiles_per_chain.txt)"),
+                                                 flops_per_utterance_sample=shb.flops, kernel=r["kernel"].split(" ")[0])
                             r["tiles_per_chain"] = tpc
                             refdef[sh.name]["multi_cu_chain_tiles_per_chain"] = r
                             if r["khz_per_utterance"] >= REALTIME_KHZ:
