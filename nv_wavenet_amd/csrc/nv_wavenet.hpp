@@ -1080,6 +1080,12 @@ public:
         if (m_implementation == SINGLE_BLOCK) assert(S <= 4 * R);
         if (!m_supported) return false;
 
+        if (init_sample == 0) {
+            // a new utterance: the dilation rings of its tiles read as zero until written (wavenet_wg takes x[t-d] = 0 for t < d
+            // from the ring itself)
+            const int tilesUsed = (batch_size + 15) / 16;
+            gpuErrChk(hipMemsetAsync(m_ring, 0, (size_t)tilesUsed * m_ringSlots * R * 16 * sizeof(elem), stream));
+        }
         wn::Params p;
         p.wblob = m_wblob;
         p.bias = m_bias;

@@ -1026,29 +1026,20 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     };
     prefetch(p.initSample, 0, p.dil[0], xpA, cdA);
     prefetch(p.initSample, 1, p.dil[1], xpB, cdB);
-    // publish this wave's fragments of the NEXT layer's dilated tap to LDS
-    // (before the start, t < d, the tap is zero -- reference :287: zeros are published then; two store sequences under
-    // a uniform branch rather than selects on the fragments, the zero case is the first d samples only)
-    auto publish_xp = [&](const frag (&xpN)[BT][XPW], const bool have) {
+    // publish this wave's fragments of the NEXT layer's dilated tap to LDS.  Before the start (t < d) the tap is zero (reference
+    // :287): the ring slot read then has not been written in this utterance, and the engine clears the rings of the tiles of a
+    // launch that starts at sample 0 (nvWavenetInfer::run_partial), so the load itself brings the zeros -- no branch here.
+    auto publish_xp = [&](const frag (&xpN)[BT][XPW]) {
 #pragma unroll
         for (int i = 0; i < XPW; i++) {
             const int k = w + NW * i;
             if (k < KF_R) {
-                if (have) {
 #pragma unroll
-                    for (int bt = 0; bt < BT; bt++) *(frag*)(xpbuf + ((bt * KF_R + k) * 64 + lane) * 16) = xpN[bt][i];
-                } else {
-                    asm volatile("");                  // (keeps this a branch)
-                    frag z;
-#pragma unroll
-                    for (int e = 0; e < P::EPL; e++) z[e] = (elem)0.f;
-#pragma unroll
-                    for (int bt = 0; bt < BT; bt++) *(frag*)(xpbuf + ((bt * KF_R + k) * 64 + lane) * 16) = z;
-                }
+                for (int bt = 0; bt < BT; bt++) *(frag*)(xpbuf + ((bt * KF_R + k) * 64 + lane) * 16) = xpN[bt][i];
             }
         }
     };
-    publish_xp(xpA, p.initSample >= 1);   // layer 0 (d = 1) of the first sample
+    publish_xp(xpA);   // layer 0 (d = 1) of the first sample
 
     __syncthreads();   // bias table visible
 
@@ -1198,7 +1189,6 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             const int lN = l + 1 < L ? l + 1 : 0;
             const float* blN = biasLds + lN * C::BIAS_L;
             const int d = dl.d;
-            const bool havePrevN = (l + 1 < L ? t : t + 1) >= dN.d;
 
             // current tap on top of bias + conditioning + dilated tap (xb: x as B fragments, requested behind the
             // x barrier)
@@ -1400,7 +1390,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 }
             // dilated tap of layer l+1 (layer 0 of the next sample after the last layer), requested one and a half layers
             // ago: shared through LDS with the x exchange (the readers of the previous tap passed the h barrier)
-            publish_xp(xpN, havePrevN);
+            publish_xp(xpN);
             __builtin_amdgcn_sched_barrier(0);
             WN_TMARK(5)
             // + conditioning of the next layer while the x stores drain (summation order of the gate pre-activation in

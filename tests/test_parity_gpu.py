@@ -255,6 +255,33 @@ def test_fp32_engine_o1_exact_samples_and_reference_bars(name, mode):
     e.close()
 
 
+@pytest.mark.parametrize("mode", ["wg", "wg3", "chain"])
+def test_a_new_utterance_starts_from_silence(mode):
+    """An engine that has generated one utterance (rings full of ITS activations) generates the next one, from other conditioning
+    and a shorter batch, exactly as a fresh engine does: the taps x[t-d] of t < d are zero (reference nv_wavenet_persistent.cuh:287).
+    wavenet_wg reads them from ring slots that run_partial clears at sample 0; the chain substitutes zeros itself."""
+    case = O1_CASES["C3"]
+    s = case.shape
+    a = util.gen_o1(case, half=True)
+    b = util.gen_o1(case._replace(seed=case.seed + 1), half=True)
+    e = _engine_o1(case, a, 16, mode)
+    y = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, s.B, y, 1, False)
+    e.setInputs(b.Lh, b.sel)
+    nb = max(1, s.B - 5)
+    y2 = np.full((s.B, s.N), -1, dtype=np.int32)              # (the output block is [maxBatch][N]; a shorter batch fills a prefix)
+    assert e.run(s.N, nb, y2, 1, False)
+    e.synchronize()
+    e.close()
+    f = _engine_o1(case, a, 16, mode, Lh=b.Lh, sel=b.sel)      # same weights, the second utterance's inputs
+    y3 = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert f.run(s.N, nb, y3, 1, False)
+    f.synchronize()
+    f.close()
+    assert not np.array_equal(y[:nb], y2[:nb])
+    assert np.array_equal(y2[:nb], y3[:nb])
+
+
 def test_chain_fills_the_gpu_by_replication():
     """The multi-CU chain with as many chains as the GPU holds (C3 fp16: 5 workgroups per 16 utterances, all of
     them resident at once, chains spread over every XCD so that some hand-offs cross XCDs): 50 tiles that repeat the
