@@ -259,7 +259,9 @@ def test_fp32_engine_o1_exact_samples_and_reference_bars(name, mode):
 def test_a_new_utterance_starts_from_silence(mode):
     """An engine that has generated one utterance (rings full of ITS activations) generates the next one, from other conditioning
     and a shorter batch, exactly as a fresh engine does: the taps x[t-d] of t < d are zero (reference nv_wavenet_persistent.cuh:287).
-    wavenet_wg reads them from ring slots that run_partial clears at sample 0; the chain substitutes zeros itself."""
+    wavenet_wg reads them from ring slots that the engine clears for a new utterance (resetHistory, i.e. every setInputs-like
+    call; a launch at sample 0 without one -- which keeps the sample history, as the reference's does -- clears them itself);
+    the chain substitutes zeros itself."""
     case = O1_CASES["C3"]
     s = case.shape
     a = util.gen_o1(case, half=True)
