@@ -1027,8 +1027,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     prefetch(p.initSample, 0, p.dil[0], xpA, cdA);
     prefetch(p.initSample, 1, p.dil[1], xpB, cdB);
     // publish this wave's fragments of the NEXT layer's dilated tap to LDS.  Before the start (t < d) the tap is zero (reference
-    // :287): the ring slot read then has not been written in this utterance, and the engine clears the rings of the tiles of a
-    // launch that starts at sample 0 (nvWavenetInfer::run_partial), so the load itself brings the zeros -- no branch here.
+    // :287): the ring slot read then has not been written in this utterance, and the engine clears the rings when a new utterance
+    // is handed over (nvWavenetInfer::resetHistory / clearRings), so the load itself brings the zeros -- no branch here.
     auto publish_xp = [&](const frag (&xpN)[BT][XPW]) {
 #pragma unroll
         for (int i = 0; i < XPW; i++) {
