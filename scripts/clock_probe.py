@@ -90,18 +90,52 @@ def read_smi():
     return out
 
 
+def read_metrics():
+    """one `rocm-smi --showmetrics` poll: the SMU's gpu_metrics table (round 5: unlike the hwmon files, which read 295 W and 2.36 GHz
+    idle or busy on these boxes, this table moves with the load) -> socket power (W), the eight XCDs' gfx clocks (MHz), the energy
+    accumulator (J) and the hotspot temperature.  ~0.5 s per poll (a process start)."""
+    out = {}
+    try:
+        r = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showmetrics"], capture_output=True, text=True, timeout=20)
+        for ln in r.stdout.split("\n"):
+            m = re.match(r"GPU\[0\]\s*:\s*([a-z_]+)[^:]*:\s*(.*)$", ln)
+            if not m:
+                continue
+            k, v = m.group(1), m.group(2).strip()
+            try:
+                if k == "current_socket_power":
+                    out["power_w"] = float(v)
+                elif k == "energy_accumulator":
+                    out["energy_j"] = float(v) * 15.259e-6
+                elif k == "current_gfxclks":
+                    mhz = [float(x) for x in re.findall(r"\d+", v)]
+                    if mhz:
+                        out["sclk_mhz"], out["sclk_mhz_min"] = sum(mhz) / len(mhz), min(mhz)
+                elif k == "temperature_hotspot":
+                    out["hotspot_c"] = float(v)
+                elif k in ("throttle_status", "indep_throttle_status") and v != "N/A":
+                    out[k] = v
+            except ValueError:
+                pass
+    except Exception as e:
+        out["rocm_smi_error"] = str(e)[:100]
+    return out
+
+
 class Sampler(threading.Thread):
-    def __init__(self):
+    def __init__(self, source="auto"):
         super().__init__(daemon=True)
         self.stop = False
         self.samples = []
-        self.fast = bool(read_sysfs())
+        self.source = source
+        if source == "auto":
+            self.source = "metrics" if "power_w" in read_metrics() else ("sysfs" if read_sysfs() else "smi")
+        self.fast = self.source == "sysfs"
 
     def run(self):
         while not self.stop:
-            t = time.perf_counter()
-            s = read_sysfs() if self.fast else read_smi()
-            s["t"] = t
+            s = {"metrics": read_metrics, "sysfs": read_sysfs, "smi": read_smi}[self.source]()
+            s["t"] = time.perf_counter()          # (stamped when the poll returns: the table is read at the end of the process start)
             self.samples.append(s)
             time.sleep(0.02 if self.fast else 0.05)
 
@@ -115,6 +149,12 @@ def summarise(samples, t0, t1):
             out[k] = sum(v) / len(v)
             out[k + "_max"] = max(v)
             out[k + "_min"] = min(v)
+    en = [(s["t"], s["energy_j"]) for s in win if "energy_j" in s]
+    if len(en) >= 2 and en[-1][0] > en[0][0]:
+        out["power_w_from_energy_accumulator"] = (en[-1][1] - en[0][1]) / (en[-1][0] - en[0][0])
+    hs = [s["hotspot_c"] for s in win if "hotspot_c" in s]
+    if hs:
+        out["hotspot_c_max"] = max(hs)
     th = [s["throttle_status"] for s in win if "throttle_status" in s]
     if th:
         out["throttle_status"] = sorted(set(str(x) for x in th))
@@ -128,6 +168,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--out", default="")
+    ap.add_argument("--telemetry", default="auto", help="auto | metrics (rocm-smi --showmetrics) | sysfs (hwmon) | smi (amd-smi / rocm-smi --showpower)")
+    ap.add_argument("--mode", default="packed", help="packed | features (conditioning computed in the kernel)")
     args = ap.parse_args()
     import torch
     import bench
@@ -150,14 +192,14 @@ def main():
         nwg = min(nwg, ncu)
         B = 16 * bt * nwg
         n = args.samples
-        e, N, keep = bench.steady_engine(w, B, n, organisation=1 + bt)
+        e, N, keep = bench.steady_engine(w, B, n, 11, None if args.mode == "packed" else args.mode, organisation=1 + bt)
         e.setClockProbe(True)
         info = e.kernelInfo(B, False)
         ms = bench.time_range(e, bench.STEADY_FROM, n, N, B)          # warm
         reps = max(1, int(args.seconds * 1e3 / ms))
-        smp = Sampler()
+        smp = Sampler(args.telemetry)
         smp.start()
-        time.sleep(0.3)                                              # idle telemetry first
+        time.sleep(0.3 if smp.fast else 2.5)                         # idle telemetry first
         t0 = time.perf_counter()
         ms = bench.time_range(e, bench.STEADY_FROM, n, N, B, reps=reps)
         t1 = time.perf_counter()
@@ -170,7 +212,8 @@ def main():
         pt = {"workgroups": nwg, "tiles_per_wg": bt, "batch": B, "kernel": info, "launches": reps, "samples_per_launch": n,
               "us_per_sample": us, "khz_per_utterance": 1e3 / us, "samples_per_sec": B * 1e6 / us,
               "shader_clock_ghz": ghz, "shader_cycles_per_sample": us * 1e3 * ghz,
-              "telemetry_source": "sysfs hwmon" if smp.fast else "amd-smi / rocm-smi", "telemetry_idle": idle, "telemetry_busy": busy}
+              "telemetry_source": {"sysfs": "sysfs hwmon", "metrics": "rocm-smi --showmetrics (gpu_metrics table)", "smi": "amd-smi / rocm-smi"}[smp.source],
+              "telemetry_idle": idle, "telemetry_busy": busy}
         doc["points"].append(pt)
         print("wgs %3d  %.2f us/sample  %.3f GHz  %.0f clk/sample  power %s W  sclk %s MHz" %
               (nwg, us, ghz, pt["shader_cycles_per_sample"], busy.get("power_w"), busy.get("sclk_mhz")), file=sys.stderr, flush=True)
