@@ -189,8 +189,9 @@ void nvw_set_chain_timeout_ms(nvw_engine* e, double ms);
 void nvw_set_clock_probe(nvw_engine* e, int on);
 double nvw_last_launch_clock_ghz(nvw_engine* e);
 /* Samples [init_sample, init_sample + count) of a num_samples-long utterance, asynchronously on `stream`
- * (one chunk of run_chunks, for hosts that drive the chunks themselves); nvw_reset_history puts the
- * sample history back to 128 like nvw_set_inputs does, without touching the conditioning. */
+ * (one chunk of run_chunks, for hosts that drive the chunks themselves); nvw_reset_history starts a new
+ * utterance -- sample history back to 128, dilation rings back to zero -- like nvw_set_inputs does, without
+ * touching the conditioning. */
 int nvw_run_range(nvw_engine* e, int init_sample, int count, int num_samples, int batch_size, void* stream);
 void nvw_reset_history(nvw_engine* e, void* stream);
 void nvw_set_selector_seed(nvw_engine* e, unsigned long long seed);
