@@ -37,6 +37,7 @@ import argparse
 import json
 import os
 import socket
+import subprocess
 import sys
 import time
 
@@ -549,6 +550,54 @@ def selftest_dist(args, world, rank, local_rank):
         sys.exit(1)
 
 
+def power_reading(e, N, NTOT, B, sptr, seconds=3.0):
+    """Socket power while the timed launch runs back to back for `seconds` (outside the timed region): the SMU's gpu_metrics table
+    through `rocm-smi --showmetrics`, polled by scripts/clock_probe.py's sampler (~5 polls per second), beside the kernel's own clock
+    probe.  The full-chip launch sits at the socket's power limit (profiles/r05_power_clock.txt): its rate is set by the joules an
+    utterance-sample costs, which is what `uj_per_utterance_sample` reports.  None when the box offers no such telemetry."""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+    try:
+        import clock_probe
+        if "power_w" not in clock_probe.read_metrics():
+            return None
+        smp = clock_probe.Sampler("metrics")
+        smp.start()
+        t0 = time.perf_counter()
+        launches = 0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(8):
+                assert e.run_partial_chunk(STEADY_FROM, N, NTOT, B, sptr)
+            launches += 8
+            torch.cuda.synchronize()
+        b.record()
+        b.synchronize()
+        t1 = time.perf_counter()
+        smp.stop = True
+        smp.join()
+        busy = clock_probe.summarise(smp.samples, t0, t1)
+        if "power_w" not in busy:
+            return None
+        ms = a.elapsed_time(b) / launches
+        out = {"socket_w": round(busy["power_w"], 1), "sclk_mhz": round(busy.get("sclk_mhz", 0.0), 1), "hotspot_c": busy.get("hotspot_c_max"),
+               "polls": busy["polls"], "seconds": round(t1 - t0, 2), "launches": launches, "ms_per_launch": ms,
+               "shader_clock_ghz": e.lastLaunchClockGHz(), "uj_per_utterance_sample": busy["power_w"] * ms * 1e-3 / (B * N) * 1e6,
+               "source": "rocm-smi --showmetrics (gpu_metrics: current_socket_power, current_gfxclks) while the timed launch repeats, "
+                         "outside the timed region"}
+        if "power_w_from_energy_accumulator" in busy:
+            out["socket_w_from_energy_accumulator"] = round(busy["power_w_from_energy_accumulator"], 1)
+        try:
+            r = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=20)
+            out["limit_w"] = float(json.loads(r.stdout)["card0"]["Max Graphics Package Power (W)"])
+        except Exception:
+            pass
+        return out
+    except Exception as ex:                          # telemetry is a courtesy of the box: never fail the benchmark for it
+        return {"error": str(ex)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -562,6 +611,7 @@ def main():
                     help="what the timed launches read: conditioning pre-packed in fragment order (the reference harness's setInputs outside "
                          "the timed region; the headline), or the upsampled features, the conditioning computed in the kernel (profiling aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the 3-second socket-power reading behind the timed steps")
     ap.add_argument("--no-extras", action="store_true", help="skip reference_definition / end_to_end / oversubscribed")
     ap.add_argument("--extras-budget", type=float, default=240.0,
                     help="seconds of wall clock the entries beside the headline may take together; what does not fit is reported as skipped")
@@ -895,6 +945,10 @@ def main():
     hist = int(torch.unique(ylast).numel())
     status = e.chainStatus()
     clock_ghz = e.lastLaunchClockGHz()          # the clock the last timed launch ran at (the chip clocks to its power budget)
+    power = None
+    if rank == 0 and world == 1 and not args.no_power:
+        note("socket power of the timed launch")
+        power = power_reading(e, N, NTOT, B, sptr)
     e.close()
 
     if rank == 0:
@@ -958,6 +1012,8 @@ def main():
             roofline["shader_clock_ghz"] = clock_ghz
             roofline["shader_cycles_per_sample"] = kern_ms * 1e-3 / N * clock_ghz * 1e9
             roofline["frac_at_measured_clock"] = roofline["frac"] * 2.4 / clock_ghz
+        if power:
+            roofline["power"] = power
         roofline["hbm"]["frac"] = roofline["hbm"]["achieved"] / HBM_PEAK_GBS
         # ... and with the dilation ring, which this design keeps in HBM (read x[t-d], write x[t]: 2 x 2R bytes per layer, utterance and
         # sample): the bytes the kernel actually asks of the memory system (what `traffic` measures), and the roof it is nearest to
