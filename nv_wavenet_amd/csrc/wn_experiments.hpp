@@ -31,7 +31,16 @@
 #define WN_REQ_AT_FEAT 6     // ... of the kernels that compute the conditioning: eighths of the (skip + conditioning) fragments under the gate (4: +0.7 %)
 #endif
 #ifndef WN_UP_PHASES
-#define WN_UP_PHASES(F16) 1     // upsample_features_kernel: phases per workgroup pass (2 = eight-wave workgroups, fp16 only; measured slower)
+#define WN_UP_PHASES(F16) 1     // upsample_features_kernel: phases per workgroup pass (2, fp16 only: measured slower)
+#endif
+#ifndef WN_UP_COLS
+#define WN_UP_COLS(F16) (WN_UP_PHASES(F16) > 1 ? 2 : 4)      // ... columns a wave takes per pass
+#endif
+#ifndef WN_UP_WAVES
+#define WN_UP_WAVES(F16) (WN_UP_PHASES(F16) > 1 ? 8 : 4)     // ... waves per workgroup
+#endif
+#ifndef WN_UP_ATTR
+#define WN_UP_ATTR              // ... extra attributes (e.g. __attribute__((amdgpu_waves_per_eu(4,4))))
 #endif
 // cache-policy bits of the buffer instructions (0 = default, 2 = nt / streaming, 16 = sc1)
 #ifndef WN_W_AUX

@@ -1854,12 +1854,14 @@ __global__ __launch_bounds__(256) void pack_features_kernel(typename Prec<F16>::
 // its four waves share the columns.
 constexpr int kUpRowTiles = (kCondChannelsMax + 15) / 16;
 // phases (PB) and columns (CB) a wave of upsample_features_kernel takes per pass, waves per workgroup.  One phase, four columns, four waves
-// ships: 0.32-0.33 ms per chunk of 256 samples x 12 288 utterances -- 0.60 GB of feature fragments written to HBM (its floor: ~0.15 ms) and
-// 2.4 GB of mel fragments read through L2.  Two phases' operands side by side in LDS (120 KiB at four taps, one workgroup per CU) halve
-// that L2 traffic and were measured slower both with four waves per workgroup (0.43 ms) and with eight (0.36-0.37 ms, same GPU call).
+// ships: 0.30 ms per chunk of 256 samples x 12 288 utterances (0.33 before the next tap's mel fragments were requested under the current
+// tap's MFMAs) -- 0.60 GB of feature fragments written to HBM (its floor: ~0.15 ms) and 2.4 GB of mel fragments read through L2.  Two
+// phases' operands side by side in LDS (120 KiB at four taps, one workgroup per CU) halve that L2 traffic and were measured slower both
+// with four waves per workgroup (0.43 ms) and with eight (0.36-0.37 ms, same GPU call); so were eight-wave workgroups of two columns
+// (0.355 ms at two waves per SIMD, 0.370 forced to four: 26 spilled registers).
 template <bool F16> constexpr int up_phases() { return WN_UP_PHASES(F16); }
-template <bool F16> constexpr int up_cols() { return up_phases<F16>() > 1 ? 2 : 4; }
-template <bool F16> constexpr int up_waves() { return up_phases<F16>() > 1 ? 8 : 4; }
+template <bool F16> constexpr int up_cols() { return WN_UP_COLS(F16); }
+template <bool F16> constexpr int up_waves() { return WN_UP_WAVES(F16); }
 // table of the A operands: [stride][kUpRowTiles][m * KFC][64 lanes][EPL] from the ConvTranspose1d weight [n_cond][n_cond][window]
 template <bool F16>
 __global__ void pack_upsample_kernel(typename Prec<F16>::elem* __restrict__ dst, const float* __restrict__ upW, int nCond, int window, int stride) {
@@ -1880,7 +1882,7 @@ __global__ void pack_upsample_kernel(typename Prec<F16>::elem* __restrict__ dst,
     }
 }
 template <bool F16>
-__global__ __launch_bounds__(64 * up_waves<F16>()) void upsample_features_kernel(typename Prec<F16>::elem* __restrict__ feat, const typename Prec<F16>::elem* __restrict__ melfrag,
+__global__ __launch_bounds__(64 * up_waves<F16>()) WN_UP_ATTR void upsample_features_kernel(typename Prec<F16>::elem* __restrict__ feat, const typename Prec<F16>::elem* __restrict__ melfrag,
                                                                 const typename Prec<F16>::elem* __restrict__ tab, const float* __restrict__ bias, int m,
                                                                 int stride, int tiles, int tilesUsed, int firstSample, int count) {
     using P = Prec<F16>;
@@ -1926,8 +1928,8 @@ __global__ __launch_bounds__(64 * up_waves<F16>()) void upsample_features_kernel
                 for (int c = 0; c < CB; c++)
 #pragma unroll
                     for (int tr = 0; tr < RTU; tr++) acc[ph][c][tr] = *(const floatx4*)(bias + tr * 16 + g * 4);
-            for (int j = 0; j < m; j++) {
-                frag b[CB][KFC];
+            // tap j's mel fragments (L2) are requested while tap j-1's MFMAs run: two register sets, the tap loop unrolled by two
+            auto load_b = [&](frag (&b)[CB][KFC], const int j) {
 #pragma unroll
                 for (int c = 0; c < CB; c++) {
                     const int fj = fcol[c] - j;
@@ -1941,6 +1943,8 @@ __global__ __launch_bounds__(64 * up_waves<F16>()) void upsample_features_kernel
                         }
                     }
                 }
+            };
+            auto taps = [&](const frag (&b)[CB][KFC], const int j) {
 #pragma unroll
                 for (int ph = 0; ph < PB; ph++)
 #pragma unroll
@@ -1951,6 +1955,16 @@ __global__ __launch_bounds__(64 * up_waves<F16>()) void upsample_features_kernel
 #pragma unroll
                             for (int c = 0; c < CB; c++) acc[ph][c][tr] = mma(a, b[c][kf], acc[ph][c][tr]);
                         }
+            };
+            frag b0[CB][KFC], b1[CB][KFC];
+            load_b(b0, 0);
+            for (int j = 0; j < m; j += 2) {
+                if (j + 1 < m) load_b(b1, j + 1);
+                taps(b0, j);
+                if (j + 1 < m) {
+                    if (j + 2 < m) load_b(b0, j + 2);
+                    taps(b1, j + 1);
+                }
             }
 #pragma unroll
             for (int ph = 0; ph < PB; ph++)
