@@ -35,3 +35,35 @@ def test_single_rank_selftest_needs_no_launcher():
     r = _run(["--selftest-dist"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
+
+
+def test_socket_telemetry_reader_parses_the_gpu_metrics_table(monkeypatch):
+    """roofline.power of bench.py and scripts/clock_probe.py read `rocm-smi --showmetrics`; the parser on a canned table (lines as a
+    GPU box printed them in round 5), the energy-accumulator power over two polls, and 'no telemetry' when the tool prints nothing."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import clock_probe
+    table = "\n".join([
+        "GPU[0]\t\t: temperature_hotspot (C): 55",
+        "GPU[0]\t\t: average_socket_power (W): N/A",
+        "GPU[0]\t\t: energy_accumulator (15.259uJ (2^-16)): 10231786994058",
+        "GPU[0]\t\t: current_gfxclk (MHz): 1990",
+        "GPU[0]\t\t: throttle_status: N/A",
+        "GPU[0]\t\t: current_socket_power (W): 1375",
+        "GPU[0]\t\t: current_gfxclks (MHz): [1990, 1997, 1957, 1967, 1948, 1990, 2001, 2010]",
+    ])
+
+    class R:
+        returncode = 0
+        stdout = table
+        stderr = ""
+    monkeypatch.setattr(clock_probe.subprocess, "run", lambda *a, **k: R)
+    m = clock_probe.read_metrics()
+    assert m["power_w"] == 1375.0 and m["hotspot_c"] == 55.0 and "throttle_status" not in m
+    assert abs(m["sclk_mhz"] - 1982.5) < 1e-9 and m["sclk_mhz_min"] == 1948.0
+    assert abs(m["energy_j"] - 10231786994058 * 15.259e-6) < 1.0
+    a = dict(m, t=10.0)
+    b = dict(m, t=12.0, energy_j=m["energy_j"] + 2750.0)
+    s = clock_probe.summarise([a, b], 9.0, 12.0)                 # (the window skips its first 30 %: both polls are inside)
+    assert abs(s["power_w_from_energy_accumulator"] - 1375.0) < 1e-6 and s["polls"] == 2
+    R.stdout = ""
+    assert "power_w" not in clock_probe.read_metrics()
