@@ -280,6 +280,66 @@ def reference_definition_khz(sh, impl, N=16384, chunk=2048):
             "kernel": info, "samples": N, "chunk": chunk, "batch": sh.B, "shader_clock_ghz": round(ghz, 3)}
 
 
+def dropin_fp32(sh, L=None, maxD=None, B=8, N=10000):
+    """The reference's own PyTorch entry, timed as its user calls it: NVWaveNet(**export_weights()).infer(cond, impl)
+    -> nv_wavenet_ext.infer -> wavenet_infer() of libwavenet_infer.so (pytorch/nv_wavenet.py:172-196, wavenet_infer.cu:105-143) -- fp32,
+    the engine built, loaded and destroyed INSIDE the call, the conditioning a CUDA tensor, libc rand() selectors -- on the workload of
+    pytorch/integration_test.py:37-52 (batch 8, 10 000 samples, conditioning of zeros there, seeded here).  Wall clock around infer(),
+    after one short call that loads the code objects; kHz per utterance = N / elapsed ms like nv_wavenet_perf.cu:87."""
+    import torch
+    from nv_wavenet_amd.nv_wavenet import NVWaveNet, Impl
+    L = L or sh.L
+    maxD = maxD or sh.maxD
+    R, S, A = sh.R, sh.S, sh.A
+    g = torch.Generator().manual_seed(5)
+    u = lambda std, *shape: ((torch.rand(*shape, generator=g) - 0.5) * (std * 12.0 ** 0.5)).cuda()
+    kw = dict(embedding_prev=u(0.45, A, R), embedding_curr=u(0.45, A, R), conv_out_weight=u(1.6 / S ** 0.5, A, S, 1),
+              conv_end_weight=u(1.5 / A ** 0.5, A, A, 1), dilate_weights=[u(0.55 / R ** 0.5, 2 * R, R, 2) for _ in range(L)],
+              dilate_biases=[u(0.3, 2 * R) for _ in range(L)], max_dilation=maxD,
+              res_weights=[u(0.5 / R ** 0.5, R, R, 1) for _ in range(L - 1)], res_biases=[u(0.05, R) for _ in range(L - 1)],
+              skip_weights=[u(1.5 / (R * L) ** 0.5, S, R, 1) for _ in range(L)], skip_biases=[u(0.3 / L ** 0.5, S) for _ in range(L)],
+              use_embed_tanh=True)
+    model = NVWaveNet(**kw)
+    out = {"definition": "NVWaveNet(**weights).infer(cond_input, impl) of the reference's PyTorch path on this library: fp32, engine construction + "
+                         "weight upload + conditioning pack + generation + teardown inside the call (wavenet_infer()); R%d S%d A%d, %d layers, "
+                         "maxDilation %d, batch %d, %d samples (pytorch/integration_test.py:37-52); wall clock, kHz per utterance"
+                         % (R, S, A, L, maxD, B, N)}
+    hw = COND_STD * 3.0 ** 0.5
+    cond = (torch.rand(2 * R, B, L, N, generator=g) * 2 - 1).mul_(hw).cuda()
+    for name, impl in (("persistent", Impl.PERSISTENT), ("auto", Impl.AUTO), ("single_block", Impl.SINGLE_BLOCK)):
+        model.infer(cond[:, :, :, :64].contiguous(), impl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = model.infer(cond, impl)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0)
+        ok = int(y.min()) >= 0 and int(y.max()) < A and int(torch.unique(y).numel()) > 8
+        out[name] = {"khz_per_utterance": (N / ms) if ok else 0.0, "ms": ms, "samples_per_sec": (B * N / ms * 1e3) if ok else 0.0}
+    del cond
+    # ... and the generation alone, for scale: the same fp32 engine through the handle API, run() of N samples (dump-free kernel)
+    w = make_weights(Shape(sh.name, R, S, A, L, maxD, B), seed=1)
+    shl = Shape(sh.name, R, S, A, L, maxD, B)
+    e = build_engine(w, B, N, sh=shl, precision=32, impl=3)
+    Lh, sel = device_inputs(B, N, 1, sh=shl)
+    e.setInputs(Lh, sel)
+    e.run(64, B)
+    e.synchronize()
+    e.setInputs(Lh, sel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e.run(N, B)
+    e.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    out["generation_only"] = {"khz_per_utterance": N / ms, "ms": ms, "kernel": e.kernelInfo(B, False)}
+    e.close()
+    del Lh, sel
+    torch.cuda.empty_cache()
+    best = max(("persistent", "auto", "single_block"), key=lambda k: out[k]["khz_per_utterance"])
+    out["khz_per_utterance"] = out["persistent"]["khz_per_utterance"]      # (what integration_test.py asks for: Impl.PERSISTENT)
+    out["best_implementation"] = best
+    return out
+
+
 def end_to_end_khz(w, B, chunk=256, chunks=4, seed=21):
     """Conditioning streamed per chunk: the fp32 [chunk][L][B][2R] block of chunk j+1 is packed into fragment
     order on a second stream while chunk j is generated; the samples of every chunk are copied to the host.
@@ -713,7 +773,7 @@ def main():
 
     # ---- beside the headline (rank 0, one GPU): the reference's own measurement on C2 / C3 / C4, the
     #      throughput organisation, and the real-time batch with conditioning streamed per chunk ----
-    refdef, thr, e2e = None, None, None
+    refdef, thr, e2e, dropin = None, None, None, None
     skipped = []
     note("workload: %d utterances per GPU, %d samples per step" % (B, N))
     if extras and rank == 0:
@@ -773,6 +833,16 @@ def main():
                             break
                     refdef[sh.name]["tiles_per_chain_sweep_steady_khz"] = sweep_mc
                 refdef[sh.name]["max_realtime_batch_multi_cu"] = best_mc
+        dropin = None
+        if extras_left() > 30:
+            note("dropin_fp32")
+            try:
+                dropin = dropin_fp32(C3)
+                dropin["integration_test_model"] = dropin_fp32(C3, L=16, maxD=128)["persistent"]      # pytorch/config.json: 16 layers, maxDilation 128
+            except Exception as ex:              # (an entry beside the headline must not take the run down)
+                dropin = {"error": str(ex)[:200]}
+        else:
+            skipped.append("dropin_fp32")
         bt = 64 * ncu                                 # four tiles per CU: not real time
         # beyond three tiles per CU a launch has more three-tile wavenet_wg workgroups than CUs (whole rounds): throughput, not real
         # time; reported at four and at six tiles per CU (= two full rounds)
@@ -1056,6 +1126,7 @@ def main():
             "c3_b16": {"khz_per_utterance": c3_b16_khz, "samples_per_sec": None if c3_b16_khz is None else 16e3 * c3_b16_khz},
             "reference_definition": refdef,
             "end_to_end": e2e,
+            "dropin_fp32": dropin,
             "oversubscribed": thr,
             "extras_skipped_for_time": skipped,
             "distinct_samples_in_last_step": hist,

@@ -40,9 +40,10 @@ typedef void (*nvw_consume_fn)(int* yOut, int init_sample, int count, void* user
 
 /* Revision of this interface.  It changes whenever an entry point or the meaning of an argument does -- in particular the
  * organisation codes of nvw_create_ex, which were renumbered once (round 3) and lost code 9 in round 4: a caller built against
- * another revision should check this instead of finding a different kernel behind a number.  5 = this header (round 5: the
- * feature-conditioning entry points below). */
-#define NVW_ABI_VERSION 5
+ * another revision should check this instead of finding a different kernel behind a number.  5 = round 5 (the
+ * feature-conditioning entry points below); 6 = this header (round 6: nvw_get_features returns int; nvw_upsample_features,
+ * nvw_generate_stream and nvw_get_features check their ranges and refuse with 0 instead of reaching the class's asserts). */
+#define NVW_ABI_VERSION 6
 int nvw_abi_version(void);
 int nvw_supported(int R, int S, int A, int precision);
 /* writes up to `max` (R,S,A,precision) quadruples into out[4*i..], returns how many exist */
@@ -167,8 +168,9 @@ int nvw_set_upsampling(nvw_engine* e, const float* up_w, const float* up_b, int 
 int nvw_set_mel(nvw_engine* e, const void* mel, int precision, long long b_stride, long long c_stride, long long f_stride, int frames);
 int nvw_upsample_features(nvw_engine* e, int first_sample, int count, void* stream);
 /* debug getter: samples [first_sample, first_sample + count) of the engine's feature buffer (what nvw_pack_features / nvw_upsample_features
- * wrote: fragment order, the engine's T_data, nvw_feature_elems(e, count) elements) -> dst (host or device); synchronises */
-void nvw_get_features(nvw_engine* e, void* dst, int first_sample, int count);
+ * wrote: fragment order, the engine's T_data, nvw_feature_elems(e, count) elements) -> dst (host or device); synchronises.
+ * 1, or 0 when refused: no feature buffer yet, or the range lies outside the engine's samples (ABI 6: returned void before) */
+int nvw_get_features(nvw_engine* e, void* dst, int first_sample, int count);
 int nvw_generate_stream(nvw_engine* e, int num_samples_per_chunk, nvw_consume_fn consume, void* user, int num_samples, int batch_size, int* yOut,
                         void* stream);
 /* the selector half of nvw_set_inputs ([num_samples][batch] uniform draws, host or device); conditioning and history untouched */

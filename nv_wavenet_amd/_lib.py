@@ -53,7 +53,7 @@ SIGNATURES = {
     "nvw_set_upsampling": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int]),
     "nvw_set_mel": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]),
     "nvw_upsample_features": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "nvw_get_features": (None, [C.c_void_p, _fp, C.c_int, C.c_int]),
+    "nvw_get_features": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "nvw_generate_stream": (C.c_int, [C.c_void_p, C.c_int, CONSUME_FN, C.c_void_p, C.c_int, C.c_int, _fp, C.c_void_p]),
     "nvw_set_selectors": (None, [C.c_void_p, _fp, C.c_int]),
     "nvw_chain_status": (C.c_uint, [C.c_void_p]),
@@ -87,7 +87,7 @@ SIGNATURES = {
     "get_A": (C.c_int, []),
 }
 
-ABI_VERSION = 5            # NVW_ABI_VERSION of include/nv_wavenet_c.h this package was written against
+ABI_VERSION = 6            # NVW_ABI_VERSION of include/nv_wavenet_c.h this package was written against
 # (checked before the other symbols are bound, so that an older library fails with the rebuild hint, not an AttributeError)
 _abi = getattr(lib, "nvw_abi_version", None)
 _have = None

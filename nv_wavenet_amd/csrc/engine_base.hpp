@@ -25,6 +25,9 @@ struct nvw_engine {
     virtual int conditioningChannels() = 0;
     virtual bool setUpsampling(const float*, const float*, int, int) = 0;
     virtual int upsamplingStride() = 0;
+    virtual int melSamples() = 0;
+    virtual bool hasFeatureBuffer() = 0;
+    virtual int maxBatch() = 0;
     virtual void getFeatures(void*, int, int) = 0;
     virtual void setMel(const void*, int, long long, long long, long long, int) = 0;
     virtual void upsampleFeatures(int, int, hipStream_t) = 0;
@@ -83,6 +86,9 @@ struct EngineImpl : nvw_engine {
     int conditioningChannels() override { return eng.conditioningChannels(); }
     bool setUpsampling(const float* W, const float* b, int window, int stride) override { return eng.setUpsampling(W, b, window, stride); }
     int upsamplingStride() override { return eng.upsamplingStride(); }
+    int melSamples() override { return eng.melSamples(); }
+    bool hasFeatureBuffer() override { return eng.hasFeatureBuffer(); }
+    int maxBatch() override { return eng.maxBatch(); }
     void getFeatures(void* d, int first, int count) override { eng.getFeatures(d, first, count); }
     void setMel(const void* mel, int prec, long long bS, long long cS, long long fS, int frames) override { eng.setMel(mel, prec, bS, cS, fS, frames); }
     void upsampleFeatures(int first, int count, hipStream_t s) override { eng.upsampleFeatures(first, count, s); }

@@ -211,8 +211,10 @@ protected:
     template <int BT> int embTables() const {
         return ldsNeed<BT>(m_numLayers, 2) <= kLdsMax ? 2 : ldsNeed<BT>(m_numLayers, 1) <= kLdsMax ? 1 : 0;
     }
-    // DUMP = false (no activation dump code at all) exists for the fp16 engine, the production path;
-    // the fp32 engine is the parity mode and always carries the dump
+    // DUMP = false (no activation dump code at all): every conditioning path of the fp16 engine (the production path); for the fp32
+    // engine -- the parity mode, and what the reference's PyTorch entry wavenet_infer() runs -- the packed-conditioning kernels and
+    // the chain (round 6: that entry has no getter that could read a dump, pytorch/wavenet_infer.h:33-58); fp32 launches that read
+    // the conditioning in place or compute it from features carry the dump code whether asked or not
     template <int BT, bool EMB, bool DUMP, int RAW> bool launchK(wn::Params& p, int tiles, int nEmb, hipStream_t stream) {
         using CB = wn::Cfg<F16, R, S, A, BT>;
         const int grid = (tiles + BT - 1) / BT;
@@ -233,8 +235,9 @@ protected:
         return p.condRawKind == 1 ? launchE<BT, DUMP, 1>(p, tiles, stream) : launchE<BT, DUMP, 0>(p, tiles, stream);
     }
     template <int BT> bool launch(wn::Params& p, int tiles, hipStream_t stream) {
-        if constexpr (F16) {
-            if (!p.dump) return launchD<BT, false>(p, tiles, stream);
+        if (!p.dump) {
+            if constexpr (F16) return launchD<BT, false>(p, tiles, stream);
+            else if (p.condRawKind == 0) return launchE<BT, false, 0>(p, tiles, stream);
         }
         return launchD<BT, true>(p, tiles, stream);
     }
@@ -259,6 +262,10 @@ protected:
     template <int BT> void allowLds() {
         allowLdsD<BT, true>();
         if constexpr (F16) allowLdsD<BT, false>();
+        else {
+            allowLdsK<BT, false, false, 0>();
+            allowLdsK<BT, true, false, 0>();
+        }
     }
     float* headBias() { return m_bias + (size_t)m_numLayers * C::BIAS_L; }
 
@@ -457,9 +464,8 @@ public:
             gpuErrChk(hipMemset(m_mail, 0, m_mailBytes));
             gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_chain<F16, R, S, A, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::ldsBytes()));
-            if constexpr (F16)
-                gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_chain<F16, R, S, A, false>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::ldsBytes()));
+            gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_chain<F16, R, S, A, false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::ldsBytes()));
             if (chainHasFallback()) {
                 gpuErrChk(hipMalloc(&m_ringShadow, ringBytes));
                 gpuErrChk(hipMalloc(&m_histShadow, 2 * (size_t)batchSize * sizeof(int)));
@@ -579,6 +585,12 @@ public:
         gpuErrChk(hipGetLastError());
         gpuErrChk(hipMemcpyAsync(m_condB, bcond, nB * sizeof(float), hipMemcpyDefault, 0));
         gpuErrChk(hipStreamSynchronize(0));
+        if (nCond != m_nCond) {
+            // the upsampling table, its bias and the mel frames were packed for the old channel count: hand them over again
+            m_upStride = 0;
+            m_upWindow = 0;
+            m_melFrames = 0;
+        }
         m_nCond = nCond;
         m_featDirty = true;
         return true;
@@ -645,12 +657,18 @@ public:
         hipLaunchKernelGGL((wn::pack_upsample_kernel<F16>), dim3(gridFor(tabElems)), dim3(256), 0, 0, m_upTab, dW, m_nCond, window, stride);
         gpuErrChk(hipGetLastError());
         gpuErrChk(hipMemcpyAsync(m_upBias, upB, m_nCond * sizeof(float), hipMemcpyDefault, 0));
+        // (per engine, hence per device: the attribute belongs to the device's copy of the kernel)
+        gpuErrChk(hipFuncSetAttribute((const void*)wn::upsample_features_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         gpuErrChk(hipStreamSynchronize(0));
+        if (stride != m_upStride) m_melFrames = 0;      // frames handed over for another stride were checked against that stride
         m_upWindow = window;
         m_upStride = stride;
         return true;
     }
     int upsamplingStride() const { return m_upStride; }
+    int melSamples() const { return m_melFrames * m_upStride; }      // samples the frames handed over with setMel upsample to (0: none)
+    bool hasFeatureBuffer() const { return m_feat != NULL; }         // the engine's own feature buffer exists (packFeatures / upsampleFeatures)
+    int maxBatch() const { return m_maxBatch; }
     // debug getter: samples [firstSample, firstSample + count) of the engine's own feature buffer (fragment order, T_data) -> dst
     void getFeatures(void* dst, int firstSample, int count) {
         assert(m_feat != NULL && firstSample >= 0 && count > 0 && firstSample + count <= m_maxSamples);
@@ -693,11 +711,6 @@ public:
         m_featSamples = m_melFrames * m_upStride;
         const int m = m_upWindow / m_upStride, tilesUsed = (m_maxBatch + 15) / 16;
         const size_t lds = (size_t)wn::up_phases<F16>() * wn::kUpRowTiles * m * KFC * 1024;      // (a pair of phases in fp16)
-        static bool allowed = false;
-        if (!allowed) {
-            gpuErrChk(hipFuncSetAttribute((const void*)wn::upsample_features_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            allowed = true;
-        }
         // a phase per workgroup; phases with few columns (long strides, short chunks) get more workgroups per phase
         const int pairs = (m_upStride + wn::up_phases<F16>() - 1) / wn::up_phases<F16>();
         const int gx = pairs < 1024 ? pairs : 1024;
@@ -955,8 +968,9 @@ public:
     // template arguments, tiles per workgroup, workgroups, dynamic LDS bytes (for benchmarks / logs).
     void kernelInfo(int batch_size, bool dumpActivations, char* buf, int n) const {
         const int tiles = (batch_size + 15) / 16;
-        const bool dump = F16 ? dumpActivations : true;
-        if (isChain() && !m_featPtr) {
+        const bool chainLaunch = isChain() && !m_featPtr;
+        const bool dump = dumpActivations || (!F16 && !chainLaunch && (m_featPtr || m_condRaw));      // (see launch())
+        if (chainLaunch) {
             const int perLaunch = m_numCUs / m_chainStages, chains = tiles < perLaunch ? tiles : perLaunch;
             snprintf(buf, n, "wn::wavenet_chain<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d tiles/chain=%d wgs=%d lds=%zu",
                      F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, chains, chainTpc((m_maxBatch + 15) / 16),
@@ -1086,7 +1100,17 @@ public:
         // itself).  resetHistory() -- every way of handing over a new utterance's conditioning calls it -- has normally done this
         // already, outside the generation's critical path; this covers run() after run() on the same inputs.
         if (init_sample == 0) clearRings(stream);
-        if ((batch_size + 15) / 16 > m_ringDirtyTiles) m_ringDirtyTiles = (batch_size + 15) / 16;
+        {
+            // the tiles whose rings this launch writes: a wavenet_wg workgroup of BT tiles stores into the rings of ALL its tiles, the
+            // padding tiles beyond the batch included (a later, larger batch must find those slots zero as well)
+            int touched = (batch_size + 15) / 16;
+            if (!(isChain() && !m_featPtr)) {
+                const int bt = wgTiles(touched);
+                touched = (touched + bt - 1) / bt * bt;
+            }
+            if (touched > m_tiles) touched = m_tiles;
+            if (touched > m_ringDirtyTiles) m_ringDirtyTiles = touched;
+        }
         wn::Params p;
         p.wblob = m_wblob;
         p.bias = m_bias;
@@ -1276,8 +1300,7 @@ protected:
         cp.timeoutTicks = m_chainTimeoutTicks;
         const int perLaunch = m_numCUs / m_chainStages;
         if (perLaunch < 1) return false;
-        bool dump = true;
-        if constexpr (F16) dump = p.dump != 0;
+        const bool dump = p.dump != 0;
         const bool fallback = m_ringShadow != NULL;
         const size_t ringTileElems = (size_t)m_ringSlots * R * 16;
         // tiles beyond the chains that are resident at once ride the same chains, up to TPC_MAX per chain (round 5); more than
@@ -1304,8 +1327,7 @@ protected:
             if (dump) {
                 hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, true>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
             } else {
-                if constexpr (F16)
-                    hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, false>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
+                hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, false>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
             }
             if (hipGetLastError() != hipSuccess) return false;
             if (fallback) {
@@ -1334,19 +1356,20 @@ protected:
     template <bool EMB> bool launchGated(wn::Params& q, int tile0, int ntiles, int nEmb, hipStream_t stream) {
         q.tileBase = tile0;
         const size_t lds = ldsNeed<1>(m_numLayers, nEmb);
-        bool dump = true;
-        if constexpr (F16) dump = q.dump != 0;
         const int kind = q.condRawKind;
+        const bool dump = q.dump != 0 || (!F16 && kind != 0);      // (see launch(): the fp32 dump-free kernel is the packed one)
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(ntiles), dim3(C::THREADS), lds, stream, q);
             return hipGetLastError() == hipSuccess;
         };
-        if constexpr (F16) {
-            if (!dump) {
+        if (!dump) {
+            if constexpr (F16) {
                 if (kind == 2) return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, false, 2>);
                 if (kind == 1) return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, false, 1>);
-                return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, false, 0>);
             }
+            return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, false, 0>);
+        }
+        if constexpr (F16) {
             if (kind == 2) return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, true, 2>);
         }
         if (kind == 1) return go(wn::wavenet_wg<F16, R, S, A, 1, EMB, true, 1>);

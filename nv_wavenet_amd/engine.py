@@ -131,7 +131,8 @@ class WavenetEngine:
         ns = self.maxSamples if numSamples is None else int(numSamples)
         assert Lh.numel() == ns * self.numLayers * self.maxBatch * 2 * self.R, "Lh has the wrong size"
         self._cond_keep = Lh
-        assert lib.nvw_set_conditioning_direct_t(self._h, addr(Lh), ns, bits)
+        if not lib.nvw_set_conditioning_direct_t(self._h, addr(Lh), ns, bits):
+            raise ValueError("nvw_set_conditioning_direct_t refused a %d-bit tensor of %d samples" % (bits, ns))
 
     def condTiles(self):
         """Tiles of 16 utterances per (sample, layer) row of the packed conditioning (the batch rounded up to whole workgroups)."""
@@ -184,14 +185,16 @@ class WavenetEngine:
         ns = x.size(2) if numSamples is None else int(numSamples)
         assert x.size(0) == self.maxBatch and x.size(1) == self.nCond and x.size(2) >= ns
         self._cond_keep = None
-        assert lib.nvw_set_features(self._h, x.data_ptr(), bits, sb, sc, st, ns)
+        if not lib.nvw_set_features(self._h, x.data_ptr(), bits, sb, sc, st, ns):
+            raise ValueError("nvw_set_features refused %s (%d samples)" % (tuple(x.shape), ns))
 
     def packFeatures(self, x, firstSample, stream=None):
         """Samples [firstSample, firstSample + x.size(2)) of the features, asynchronously on `stream`; history untouched."""
         bits, sb, sc, st = self._feat_args(x)
         assert x.size(0) == self.maxBatch and x.size(1) == self.nCond
         self._cond_keep = None
-        assert lib.nvw_pack_features(self._h, x.data_ptr(), bits, sb, sc, st, int(firstSample), x.size(2), stream)
+        if not lib.nvw_pack_features(self._h, x.data_ptr(), bits, sb, sc, st, int(firstSample), x.size(2), stream):
+            raise ValueError("nvw_pack_features refused samples [%d, %d)" % (firstSample, firstSample + x.size(2)))
 
     def setConditioningFeatures(self, frags, numSamples=None):
         """Features already in fragment order: CUDA tensor [numSamples][condTiles()][featureFragments()][64][8 fp16 | 4 fp32] of the
@@ -226,7 +229,8 @@ class WavenetEngine:
         self.melFrames = mel.size(2)
 
     def upsampleFeatures(self, firstSample, count, stream=None):
-        assert lib.nvw_upsample_features(self._h, int(firstSample), int(count), stream)
+        if not lib.nvw_upsample_features(self._h, int(firstSample), int(count), stream):
+            raise ValueError("nvw_upsample_features refused samples [%d, %d)" % (firstSample, firstSample + count))
 
     def getFeatures(self, firstSample, count):
         """Debug getter: the engine's own feature fragments of samples [firstSample, firstSample + count) as a CUDA tensor
@@ -235,7 +239,8 @@ class WavenetEngine:
         epl = 8 if self.precision == 16 else 4
         out = torch.empty(count, self.condTiles(), self.featureFragments(), 4, 16, epl, device="cuda",
                           dtype=torch.float16 if self.precision == 16 else torch.float32)
-        lib.nvw_get_features(self._h, out.data_ptr(), int(firstSample), int(count))
+        if not lib.nvw_get_features(self._h, out.data_ptr(), int(firstSample), int(count)):
+            raise ValueError("nvw_get_features refused samples [%d, %d)" % (firstSample, firstSample + count))
         return out
 
     def generate_stream(self, num_samples_per_chunk, consume, num_samples, batch_size, yOut=None, stream=None):

@@ -6,13 +6,14 @@ libwavenet_infer.so, to prove the drop-in claim of INTEGRATION.md 2a by compilin
                                      edits INTEGRATION.md documents for current PyTorch (no <THC/THC.h>,
                                      .data<T>() -> .data_ptr<T>()), compiled against the REFERENCE's own
                                      pytorch/wavenet_infer.h and linked to nv_wavenet_amd/libwavenet_infer.so
-  oracle/_ref/nv_wavenet_ref.pyc  <- byte-compiled /root/reference/pytorch/nv_wavenet.py, unchanged
 
 The patched copy of the wrapper lives in a temporary directory only; nothing of the reference's sources enters the
-repository (oracle/_ref/ is git-ignored build output that travels to the GPU box like our own .so files).
-tests/test_parity_gpu.py::test_reference_binding_runs_unchanged imports both on the GPU box."""
+repository (oracle/_ref/ is git-ignored build output -- a compiled .so -- that travels to the GPU box like our own .so files).
+The reference's PYTHON side (pytorch/nv_wavenet.py) does not travel in any form: no copy, no bytecode (rounds 4-5 shipped a .pyc of
+it; removed in round 6, and a stale one is deleted here).  It is imported where it lies, in the authoring container only
+(tests/test_capi_cpu.py::test_reference_python_wrapper_prepares_the_same_tensors); on the GPU box the reference's compiled
+extension is driven by this repo's mirror of that class (tests/test_parity_gpu.py::test_reference_pybind_extension_on_this_library)."""
 import os
-import py_compile
 import subprocess
 import sys
 import sysconfig
@@ -24,6 +25,9 @@ REF = os.environ.get("REFERENCE", "/root/reference")
 
 
 def main():
+    stale = os.path.join(HERE, "_ref", "nv_wavenet_ref.pyc")
+    if os.path.exists(stale):
+        os.remove(stale)
     src = os.path.join(REF, "pytorch", "wavenet_infer_wrapper.cpp")
     if not os.path.exists(src):
         print("reference tree %s absent: keeping prebuilt oracle/_ref binding (if any)" % REF)
@@ -56,9 +60,6 @@ def main():
                     "-Wl,-rpath,$ORIGIN/../../nv_wavenet_amd", "-Wl,-rpath," + tlib]
             subprocess.check_call(cmd)
         print("built oracle/_ref/nv_wavenet_ext.so from %s" % src)
-    py = os.path.join(REF, "pytorch", "nv_wavenet.py")
-    py_compile.compile(py, cfile=os.path.join(out_dir, "nv_wavenet_ref.pyc"), doraise=True)
-    print("byte-compiled %s -> oracle/_ref/nv_wavenet_ref.pyc" % py)
     return 0
 
 

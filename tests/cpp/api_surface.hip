@@ -1,7 +1,18 @@
-// Compile-only translation unit (tests/test_capi_cpu.py): a reference-style host program written against
-// nv_wavenet.hpp exactly as /root/reference/nv_wavenet_test.cu:44-329 and pytorch/wavenet_infer.cu:40-100 are
-// written against nv_wavenet.cuh -- every public member of nvWavenetInfer with the reference's defaults
-// (nv_wavenet.cuh:311,396-444,636-639), a lambda run_chunks consumer, both precisions.
+// A reference-style host program written against nv_wavenet.hpp exactly as /root/reference/nv_wavenet_test.cu:44-329 and
+// pytorch/wavenet_infer.cu:40-100 are written against nv_wavenet.cuh -- every public member of nvWavenetInfer with the
+// reference's defaults (nv_wavenet.cuh:311,396-444,636-639), a lambda run_chunks consumer, both precisions.
+//   * compile-only in tests/test_capi_cpu.py (hipcc cross-compiles without a GPU);
+//   * built into tests/cpp/api_surface by __graft_entry__.build() and RUN on the GPU by
+//     tests/test_parity_gpu.py::test_native_host_program_against_the_c_abi (round 6; role of nv_wavenet_test.cu:331-395 as a native
+//     binary): `api_surface` alone drives the whole surface on zero weights and exits 0 when every call returned true;
+//     `api_surface run <precision 32|16> <impl> <L> <maxD> <B> <N> <out.bin>` generates from a seeded model (wn_test_uniform below,
+//     restated in numpy by the test) through the CLASS -- run, then run_chunks with a lambda consumer, which must agree -- and writes
+//     yOut [B][N] int32, which the test compares with the C-ABI run of the same tensors and, in fp32, with the oracle
+//     (nv_wavenet_test.cu:302-304 is the bar: identical samples).
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
 #include <vector>
 
 #include "nv_wavenet.hpp"
@@ -77,7 +88,76 @@ static_assert(stream_layout_ok<wn::Cfg<true, 64, 256, 256, 3, wn::feat_kfc<true>
                   wn::Cfg<true, 64, 256, 256, 3, 3>::FLW == 24 && wn::feat_kfc<true>() == 3 && wn::feat_kfc<false>() == 5,
               "Cfg<.., KFC>::streamPos is not a permutation of the layer fragments");
 
-int main() {
+// uniform [0,1) of (tensor id, element index): a counter-based hash (splitmix64 finaliser), so that numpy restates it elementwise
+static inline float wn_test_uniform(uint32_t tensor, uint64_t i) {
+    uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)tensor * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+static std::vector<float> wn_test_tensor(uint32_t id, size_t n, float scale) {      // uniform in [-scale, scale)
+    std::vector<float> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = (2.0f * wn_test_uniform(id, i) - 1.0f) * scale;
+    return v;
+}
+
+// tensor ids: 1 embPrev, 2 embCur, 3 Wzs, 4 Bzs, 5 Wza, 6 Bza, 7 Lh, 8 selectors (plain [0,1)), 100 + 7*l + {0..6}: Wprev Wcur Bh Wres Bres Wskip Bskip
+template <typename T_weight, typename T_data, int R, int S, int A>
+static int generate(int impl, int L, int maxD, int B, int N, const char* out) {
+    typedef nvWavenetInfer<T_weight, T_data, R, S, A> Infer;
+    Infer infer(L, maxD, B, N, impl);
+    const float sR = sqrtf(3.0f / R), sS = sqrtf(3.0f / S), sA = sqrtf(3.0f / A);
+    std::vector<float> embP = wn_test_tensor(1, (size_t)A * R, 1.0f), embC = wn_test_tensor(2, (size_t)A * R, 1.0f);
+    infer.setEmbeddings(embP.data(), embC.data());
+    for (int l = 0; l < L; l++) {
+        const uint32_t id = 100 + 7 * l;
+        std::vector<float> Wprev = wn_test_tensor(id, (size_t)2 * R * R, sR), Wcur = wn_test_tensor(id + 1, (size_t)2 * R * R, sR),
+                           Bh = wn_test_tensor(id + 2, 2 * R, 0.1f), Wres = wn_test_tensor(id + 3, (size_t)R * R, sR),
+                           Bres = wn_test_tensor(id + 4, R, 0.1f), Wskip = wn_test_tensor(id + 5, (size_t)S * R, sR),
+                           Bskip = wn_test_tensor(id + 6, S, 0.1f);
+        infer.setLayerWeights(l, Wprev.data(), Wcur.data(), Bh.data(), Wres.data(), Bres.data(), Wskip.data(), Bskip.data());
+        // (the caller may free its buffers as soon as a set* call returns: nv_wavenet_test.cu:143-144)
+    }
+    std::vector<float> Wzs = wn_test_tensor(3, (size_t)A * S, sS), Bzs = wn_test_tensor(4, A, 0.1f),
+                       Wza = wn_test_tensor(5, (size_t)A * A, 4.0f * sA), Bza = wn_test_tensor(6, A, 0.1f);
+    infer.setOutWeights(Wzs.data(), Bzs.data(), Wza.data(), Bza.data());
+    std::vector<float> Lh = wn_test_tensor(7, (size_t)N * L * B * 2 * R, 0.5f), sel((size_t)N * B);
+    for (size_t i = 0; i < sel.size(); i++) sel[i] = wn_test_uniform(8, i);
+    infer.setInputs(Lh.data(), sel.data());
+
+    std::vector<int> y((size_t)B * N, -1), y2((size_t)B * N, -2);
+    const int bspb = (B % 4) == 0 ? 4 : (B % 2) == 0 ? 2 : 1;                   // as pytorch/wavenet_infer.cu:96 picks it
+    bool ok = infer.run(N, B, y.data(), bspb, true);
+    gpuErrChk(hipDeviceSynchronize());
+    std::vector<float> p((size_t)B * A);
+    infer.getP(p.data());                                                        // the dump of the last sample: a distribution
+    for (int b = 0; b < B; b++) {
+        double sum = 0;
+        for (int a = 0; a < A; a++) sum += p[(size_t)b * A + a];
+        ok = ok && fabs(sum - 1.0) < 1e-3;
+    }
+    int consumed = 0;
+    infer.setInputs(Lh.data(), sel.data());                                      // a new utterance: history back to silence
+    ok = infer.run_chunks((N + 2) / 3, [&consumed](int*, int, int count) { consumed += count; }, N, B, y2.data(), bspb) && ok;
+    ok = ok && consumed == N && memcmp(y.data(), y2.data(), y.size() * sizeof(int)) == 0;
+    FILE* f = fopen(out, "wb");
+    if (!f) return 3;
+    fwrite(y.data(), sizeof(int), y.size(), f);
+    fclose(f);
+    return ok ? 0 : 2;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 2 && strcmp(argv[1], "run") == 0) {
+        if (argc != 9) {
+            fprintf(stderr, "usage: %s run <precision 32|16> <impl 0..4> <L> <maxD> <B> <N> <out.bin>   (R=64 S=128 A=256)\n", argv[0]);
+            return 64;
+        }
+        const int prec = atoi(argv[2]), impl = atoi(argv[3]), L = atoi(argv[4]), maxD = atoi(argv[5]), B = atoi(argv[6]), N = atoi(argv[7]);
+        return prec == 16 ? generate<half2, half, 64, 128, 256>(impl, L, maxD, B, N, argv[8])
+                          : generate<float, float, 64, 128, 256>(impl, L, maxD, B, N, argv[8]);
+    }
     bool ok = drive<float, float, 64, 128, 256>(4, 4, 16, 1);      // the default R,S,A of the class template
     ok = drive<half2, half, 64, 128, 256>(4, 4, 16, 3) && ok;
     typedef nvWavenetInfer<float, float> Defaults;                 // template defaults R=64, S=128, A=256

@@ -160,8 +160,9 @@ def test_reference_style_host_program_compiles_against_nv_wavenet_hpp():
 
 def test_reference_binding_is_built_when_the_reference_tree_is_here():
     """oracle/build_ref_binding.py compiles the reference's own pybind wrapper (pytorch/wavenet_infer_wrapper.cpp with
-    the two documented edits) against libwavenet_infer.so and byte-compiles its nv_wavenet.py; the extension
-    imports and reports the compiled channel counts without a GPU.  (The GPU test runs inference through it.)"""
+    the two documented edits) against libwavenet_infer.so; the extension imports and reports the compiled channel
+    counts without a GPU.  (The GPU test runs inference through it.)  No bytecode of the reference's Python is left
+    beside it: that file does not travel."""
     import subprocess
     import sys
     if not os.path.exists("/root/reference/pytorch/wavenet_infer_wrapper.cpp"):
@@ -171,4 +172,47 @@ def test_reference_binding_is_built_when_the_reference_tree_is_here():
             "print(m.num_res_channels(), m.num_skip_channels(), m.num_out_channels())") % os.path.join(ROOT, "oracle", "_ref")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.split() == ["64", "256", "256"], out.stderr[-2000:]
-    assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", "nv_wavenet_ref.pyc"))
+    assert not [f for f in os.listdir(os.path.join(ROOT, "oracle", "_ref")) if f.endswith((".pyc", ".py"))]
+
+
+def test_reference_python_wrapper_prepares_the_same_tensors():
+    """The reference's OWN pytorch/nv_wavenet.py, imported where it lies (this container only: it does not travel), against this
+    package's mirror of it (nv_wavenet_amd/nv_wavenet.py): for the same exported weights both classes hand the extension the same
+    tensors -- embeddings, output matrices, the 7-per-layer list in the same order with the same column-major images and the
+    zero-padded last residual layer --, report the same channel counts and layer count, and turn a conditioning tensor into the same
+    [N][L][B][2R] image (column_major).  What follows `nv_wavenet_ext.infer(...)` is the C ABI both share."""
+    import sys
+    import importlib.util
+    import torch
+    ref_py = "/root/reference/pytorch/nv_wavenet.py"
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    if not (os.path.exists(ref_py) and os.path.exists(os.path.join(refdir, "nv_wavenet_ext.so"))):
+        pytest.skip("no reference tree (or no compiled reference extension) on this machine")
+    sys.path.insert(0, refdir)                      # the reference's file imports `nv_wavenet_ext` at its top
+    try:
+        spec = importlib.util.spec_from_file_location("nv_wavenet_reference_py", ref_py)
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+    finally:
+        sys.path.remove(refdir)
+        sys.modules.pop("nv_wavenet_ext", None)
+    from nv_wavenet_amd import nv_wavenet as ours
+    R, S, A, L = 64, 256, 256, 5
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *shape: torch.randn(*shape, generator=g)
+    kw = dict(embedding_prev=rnd(A, R), embedding_curr=rnd(A, R), conv_out_weight=rnd(A, S, 1), conv_end_weight=rnd(A, A, 1),
+              dilate_weights=[rnd(2 * R, R, 2) for _ in range(L)], dilate_biases=[rnd(2 * R) for _ in range(L)], max_dilation=4,
+              res_weights=[rnd(R, R, 1) for _ in range(L - 1)], res_biases=[rnd(R) for _ in range(L - 1)],
+              skip_weights=[rnd(S, R, 1) for _ in range(L)], skip_biases=[rnd(S) for _ in range(L)], use_embed_tanh=False)
+    a, b = ref.NVWaveNet(**kw), ours.NVWaveNet(**kw)
+    assert (a.R, a.S, a.A, a.num_layers, a.max_dilation, a.use_embed_tanh) == (b.R, b.S, b.A, b.num_layers, b.max_dilation, b.use_embed_tanh)
+    for name in ("embedding_prev", "embedding_curr", "conv_out", "conv_end"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert x.shape == y.shape and x.is_contiguous() and y.is_contiguous() and torch.equal(x, y), name
+    assert len(a.layers) == len(b.layers) == 7 * L
+    for i, (x, y) in enumerate(zip(a.layers, b.layers)):
+        assert x.shape == y.shape and torch.equal(x.contiguous(), y.contiguous()) and y.is_contiguous(), "layers[%d]" % i
+    cond = rnd(2 * R, 3, L, 7)
+    assert torch.equal(ref.column_major(cond), ours.column_major(cond))
+    assert (ref.Impl.AUTO, ref.Impl.SINGLE_BLOCK, ref.Impl.DUAL_BLOCK, ref.Impl.PERSISTENT) == \
+           (int(ours.Impl.AUTO), int(ours.Impl.SINGLE_BLOCK), int(ours.Impl.DUAL_BLOCK), int(ours.Impl.PERSISTENT))

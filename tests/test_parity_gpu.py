@@ -284,6 +284,38 @@ def test_a_new_utterance_starts_from_silence(mode):
     assert np.array_equal(y2[:nb], y3[:nb])
 
 
+@pytest.mark.parametrize("mode", ["wg3", "wg2", "auto"])
+def test_a_larger_batch_after_a_smaller_one_starts_from_silence(mode):
+    """The batch GROWS between utterances: a workgroup of two or three tiles stores into the rings of ALL its tiles, the
+    padding tiles beyond the batch included, so a small batch dirties ring slots of tiles it does not generate.  A following utterance
+    with a larger batch must find them zero (taps x[t-d] of t < d: reference nv_wavenet_persistent.cuh:287): same samples as a fresh
+    engine.  (The engine records the tiles a launch touches, rounded up to its tiles per workgroup.)"""
+    case = O1_CASES["C3"]
+    s = case.shape
+    a = util.gen_o1(case, half=True)
+    b = util.gen_o1(case._replace(seed=case.seed + 1), half=True)
+    B = 48
+    idx = np.arange(B) % s.B
+    rep = lambda t: (np.ascontiguousarray(t.Lh[:, :, idx, :]), np.ascontiguousarray(t.sel[:, idx]))
+    LhA, selA = rep(a)
+    LhB, selB = rep(b)
+    e = _engine_o1(case, a, 16, mode, B=B, Lh=LhA, sel=selA)
+    y = np.full((B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, 16, y, 1, False)                         # one tile of the batch; a three-tile workgroup writes the rings of three
+    e.setInputs(LhB, selB)
+    y2 = np.full((B, s.N), -1, dtype=np.int32)
+    assert e.run(s.N, B, y2, 1, False)
+    e.synchronize()
+    e.close()
+    f = _engine_o1(case, a, 16, mode, B=B, Lh=LhB, sel=selB)
+    y3 = np.full((B, s.N), -1, dtype=np.int32)
+    assert f.run(s.N, B, y3, 1, False)
+    f.synchronize()
+    f.close()
+    assert np.array_equal(y2, y3)
+    assert np.array_equal(y2[:16], y2[16:32]) and np.array_equal(y2[:16], y2[32:])      # (the three tiles repeat the same utterances)
+
+
 def test_chain_fills_the_gpu_by_replication():
     """The multi-CU chain with as many chains as the GPU holds (C3 fp16: 5 workgroups per 16 utterances, all of
     them resident at once, chains spread over every XCD so that some hand-offs cross XCDs): 50 tiles that repeat the
@@ -767,41 +799,47 @@ def test_wavenet_infer_c_abi_and_python_wrapper():
     o.close()
 
 
-def test_reference_binding_runs_unchanged():
-    """The drop-in claim, proven by running the reference side: the reference's own pybind extension
-    (pytorch/wavenet_infer_wrapper.cpp, compiled by oracle/build_ref_binding.py against libwavenet_infer.so) and its
-    own pytorch/nv_wavenet.py (byte-compiled, unchanged) generate through this engine, and the samples equal both the
-    oracle's (same libc rand() draws) and the ctypes mirror's."""
+def test_reference_pybind_extension_on_this_library():
+    """The drop-in claim at the binding level: the reference's own pybind extension (pytorch/wavenet_infer_wrapper.cpp, compiled by
+    oracle/build_ref_binding.py against libwavenet_infer.so -- a compiled .so under oracle/_ref) generates through this engine when
+    it is handed what the reference's NVWaveNet class hands it, and the samples equal both the oracle's (same libc rand() draws)
+    and the ctypes module's.  The class driving it here is this repo's mirror (nv_wavenet_amd/nv_wavenet.py); the reference's own
+    Python file does not travel to the GPU box in any form -- tests/test_capi_cpu.py::
+    test_reference_python_wrapper_prepares_the_same_tensors imports it where it lies (authoring container) and holds the mirror
+    to it tensor by tensor."""
     import ctypes
     import os
     import sys
-    import importlib.util
-    from importlib.machinery import SourcelessFileLoader
     import torch
     from oracle import oracle as O
+    import nv_wavenet_amd.nv_wavenet as mirror_mod
+    from nv_wavenet_amd.nv_wavenet import NVWaveNet, Impl
     refdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
-    if not (os.path.exists(os.path.join(refdir, "nv_wavenet_ext.so")) and os.path.exists(os.path.join(refdir, "nv_wavenet_ref.pyc"))):
+    if not os.path.exists(os.path.join(refdir, "nv_wavenet_ext.so")):
         pytest.skip("oracle/_ref binding not built (needs the reference tree at build time)")
+    assert not os.path.exists(os.path.join(refdir, "nv_wavenet_ref.pyc")), "bytecode of the reference's Python must not travel"
     sys.path.insert(0, refdir)
     try:
-        import nv_wavenet_ext as ref_ext            # the REFERENCE's extension module
-        loader = SourcelessFileLoader("nv_wavenet_ref", os.path.join(refdir, "nv_wavenet_ref.pyc"))
-        spec = importlib.util.spec_from_loader("nv_wavenet_ref", loader)
-        ref_py = importlib.util.module_from_spec(spec)
-        loader.exec_module(ref_py)                  # the REFERENCE's nv_wavenet.py
+        import nv_wavenet_ext as ref_ext            # the REFERENCE's extension module (compiled C++)
     finally:
         sys.path.remove(refdir)
+    assert ref_ext.__file__.startswith(refdir)
     assert (ref_ext.num_res_channels(), ref_ext.num_skip_channels(), ref_ext.num_out_channels()) == (64, 256, 256)
     R, S, A, L, B, N, maxD = 64, 256, 256, 6, 3, 24, 4
     w, dev, cond = _wrapper_model(R, S, A, L, B, N)
     libc = ctypes.CDLL("libc.so.6")
-    model = ref_py.NVWaveNet(**dev)
     cond_dev = cond.cuda()
-    model.infer(cond_dev, ref_py.Impl.PERSISTENT)      # warm-up: the HIP runtime draws from rand() when it loads code
-    torch.cuda.synchronize()
-    libc.srand(1234)
-    y = model.infer(cond_dev, ref_py.Impl.PERSISTENT)
-    torch.cuda.synchronize()
+    ours = mirror_mod.nv_wavenet_ext
+    try:
+        mirror_mod.nv_wavenet_ext = ref_ext         # the mirror class now calls the reference's pybind entry point
+        model = NVWaveNet(**dev)
+        model.infer(cond_dev, Impl.PERSISTENT)      # warm-up: the HIP runtime draws from rand() when it loads code
+        torch.cuda.synchronize()
+        libc.srand(1234)
+        y = model.infer(cond_dev, Impl.PERSISTENT)
+        torch.cuda.synchronize()
+    finally:
+        mirror_mod.nv_wavenet_ext = ours
     y = y.cpu().numpy()
     O._lib("oracle").nvw_srand(1234)
     sel = np.zeros((N, B), dtype=np.float32)
@@ -810,11 +848,75 @@ def test_reference_binding_runs_unchanged():
     o = _wrapper_oracle(w, cond, R, S, A, L, B, N, maxD, sel)
     assert np.array_equal(y, o.run(N)), "the reference's binding on this engine disagrees with the oracle"
     o.close()
-    from nv_wavenet_amd.nv_wavenet import NVWaveNet, Impl
-    mirror = NVWaveNet(**dev)
+    mirror = NVWaveNet(**dev)                       # ... and through this package's ctypes module of the same name
     libc.srand(1234)
     y2 = mirror.infer(cond_dev, Impl.PERSISTENT).cpu().numpy()
     assert np.array_equal(y, y2)
+
+
+def _native_uniform(tensor_id, n):
+    """wn_test_uniform of tests/cpp/api_surface.hip (splitmix64 finaliser of (tensor id, index)), elementwise."""
+    with np.errstate(over="ignore"):
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        z = i * np.uint64(0x9E3779B97F4A7C15) + np.uint64(tensor_id) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def _native_inputs(R, S, A, L, B, N):
+    """The seeded model of `api_surface run` (generate<> there), in the oracle's TestInputs layout."""
+    from oracle import oracle as O
+    t = O.TestInputs(R, S, A, L, B, N)
+    f32 = np.float32
+
+    def fill(a, tid, scale):
+        a.reshape(-1)[:] = (f32(2.0) * _native_uniform(tid, a.size) - f32(1.0)) * f32(scale)
+    sR, sS, sA = f32(np.sqrt(f32(3.0) / f32(R))), f32(np.sqrt(f32(3.0) / f32(S))), f32(np.sqrt(f32(3.0) / f32(A)))
+    fill(t.embP, 1, 1.0), fill(t.embC, 2, 1.0)
+    for l in range(L):
+        tid = 100 + 7 * l
+        for k, (arr, sc) in enumerate(((t.Wprev[l], sR), (t.Wcur[l], sR), (t.Bh[l], 0.1), (t.Wres[l], sR), (t.Bres[l], 0.1),
+                                       (t.Wskip[l], sR), (t.Bskip[l], 0.1))):
+            fill(arr, tid + k, sc)
+    fill(t.Wzs, 3, sS), fill(t.Bzs, 4, 0.1), fill(t.Wza, 5, f32(4.0) * sA), fill(t.Bza, 6, 0.1), fill(t.Lh, 7, 0.5)
+    t.sel.reshape(-1)[:] = _native_uniform(8, t.sel.size)
+    return t
+
+
+@pytest.mark.parametrize("precision,impl,L,maxD,B,N", [(32, 1, 6, 8, 5, 40), (32, 3, 7, 4, 16, 33), (16, 1, 6, 8, 20, 40), (16, 3, 8, 16, 4, 50)])
+def test_native_host_program_against_the_c_abi(precision, impl, L, maxD, B, N, tmp_path):
+    """A C++ host written against the CLASS (tests/cpp/api_surface.hip, compiled by __graft_entry__.build(); role of
+    nv_wavenet_test.cu:331-395 as a native binary) is EXECUTED on the GPU: first the whole public surface (every member, the
+    reference's defaults, lambda consumers, both precisions), then a seeded generation whose yOut must equal the C-ABI run of the
+    same tensors (nv_wavenet_test.cu:302-304: identical samples) and, in fp32, the oracle's; inside the binary run() and
+    run_chunks() with a lambda consumer must agree and the dumped distribution must sum to one."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "api_surface")
+    assert os.path.exists(exe), "tests/cpp/api_surface is built by __graft_entry__.build()"
+    if (precision, impl) == (32, 1):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, "surface drive failed (%d): %s" % (r.returncode, r.stderr[-2000:])
+    out = str(tmp_path / "y.bin")
+    r = subprocess.run([exe, "run", str(precision), str(impl), str(L), str(maxD), str(B), str(N), out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "native run failed (%d): %s" % (r.returncode, r.stderr[-2000:])
+    y_native = np.fromfile(out, dtype=np.int32).reshape(B, N)
+    R, S, A = 64, 128, 256
+    t = _native_inputs(R, S, A, L, B, N)
+    case = cases.Case("native", 0, [], cases.Shape(R, S, A, L, B, N, maxD), impl, 1, N)
+    e = util.make_engine(case, t, precision=precision)
+    y = np.full((B, N), -1, dtype=np.int32)
+    assert e.run(N, B, y, 1, False)
+    e.synchronize()
+    e.close()
+    assert np.array_equal(y_native, y), "the class driven natively and the C ABI disagree"
+    assert all(len(np.unique(y[b])) > 4 for b in range(B))          # (a seeded model, not a constant)
+    if precision == 32:
+        o = util.make_oracle(case, t)
+        assert np.array_equal(y, o.run(N)), "fp32 samples differ from the oracle"
+        o.close()
 
 
 def test_persistent_python_wrapper_seeded_audio():
