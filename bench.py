@@ -72,8 +72,9 @@ HEAD = C3                                     # the shape the headline metric is
 R, S, A, L, MAXD = HEAD.R, HEAD.S, HEAD.A, HEAD.L, HEAD.maxD
 # the device code the engine launches for the headline point (asserted against nvw_kernel_info, and pinned
 # by tests/test_parity_gpu.py::test_benchmarked_launch_*: the timed kernel is the parity-tested one)
-HEADLINE_KERNELS = {2: "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=1,DUMP=0,RAW=0>",     # by tiles per workgroup
-                    3: "wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0,RAW=0>"}
+HEADLINE_KERNELS = {2: "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=2,DUMP=0,RAW=0>",     # by tiles per workgroup
+                    3: "wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0,RAW=0>",
+                    4: "wn::wavenet_wg<fp16,64,256,256,BT=4,EMBLDS=0,DUMP=0,RAW=0>"}
 HEADLINE_KERNEL = HEADLINE_KERNELS[2]
 
 
@@ -610,6 +611,55 @@ def selftest_dist(args, world, rank, local_rank):
         sys.exit(1)
 
 
+def energy_roofline(power, kern_ms, B, N, bt, features=False):
+    """The roof that binds the full-chip launch: the socket's power limit.  At the limit a sample takes
+    (joules it costs) / (watts the socket grants), so the figure of merit is energy per utterance-sample against the energy the
+    ALGORITHM needs at this chip's prices -- the marginal energy of an MFMA, a vector instruction, a transcendental, an LDS / L2 / HBM
+    byte, measured by scripts/energy_ubench.py at the headline kernel's occupancy (profiles/r06_energy_ubench.json/.txt).
+      achieved_uj = (socket W while the timed launch repeats - socket W of resident, idle waves) x seconds per launch / utterance-samples
+      floor_uj    = SURVEY.md 8(d)'s algorithmic counts per utterance-sample x those prices: MACs (as 16x16x32 MFMAs), transcendentals,
+                    the vector operations of gate / ReLU / softmax / conversions, LDS bytes of the activation exchanges, the weight
+                    stream of this organisation (weights per pass / utterances per pass), compulsory HBM bytes
+    and `floor_with_ring_uj` adds the dilation ring this design keeps in HBM (read x[t-d], write x[t])."""
+    path = os.path.join(ROOT, "profiles", "r06_energy_ubench.json")
+    if not power or "socket_w" not in power or not os.path.exists(path):
+        return None
+    try:
+        doc = json.load(open(path))
+        pr = doc["prices"]["256"]
+        nj = lambda k: pr[k]["pj_per_op"] * 1e-3                       # nJ per op
+        base_w = pr["loop"]["socket_w"]
+        units = B * N
+        achieved_total = power["socket_w"] * power["ms_per_launch"] * 1e-3 / units * 1e6
+        achieved = (power["socket_w"] - base_w) * power["ms_per_launch"] * 1e-3 / units * 1e6
+        sh = HEAD
+        mfma = sh.macs / 8192.0                                          # v_mfma_f32_16x16x32_f16 per utterance-sample
+        trans = (2 * sh.R * sh.L + sh.R + sh.A) / 64.0                   # wave instructions (64 lanes)
+        # vector operations per utterance-sample: gate (two adds, an fma, a product per output), fp16 conversions of x / h / skip / zs,
+        # ReLUs, softmax (fma, add, compare, add per logit)
+        valu = (4 * sh.R * sh.L + 2 * sh.R * sh.L + 2 * (sh.S + sh.A) + 4 * sh.A) / 64.0
+        lds_b = lds_bytes_per_sample(bt) / (16.0 * bt)
+        w_b = sh.weight_bytes / (16.0 * bt)
+        hbm_r = (2 * 96 + 4) if features else (sh.hbm_bytes - 4)
+        ring_b = 2 * sh.R * sh.L                                          # read, and as much written
+        parts = {"mfma": mfma * nj("mfma16") * 1e-3, "transcendental": trans * nj("trans") * 1e-3, "valu": valu * nj("valu") * 1e-3,
+                 "lds": lds_b / 1024.0 * nj("lds") * 1e-3, "l2_weight_stream": w_b / 1024.0 * nj("l2") * 1e-3,
+                 "hbm_compulsory": (hbm_r / 1024.0 * nj("hbm") + 4 / 1024.0 * nj("hbmw")) * 1e-3}
+        ring = (ring_b / 1024.0 * nj("hbm") + ring_b / 1024.0 * nj("hbmw")) * 1e-3
+        floor = sum(parts.values())
+        return {"unit": "uJ per utterance-sample", "achieved_uj": achieved, "achieved_total_uj": achieved_total, "floor_uj": floor,
+                "frac": floor / achieved, "floor_with_ring_uj": floor + ring, "frac_with_ring": (floor + ring) / achieved,
+                "floor_parts_uj": {k: round(v, 4) for k, v in parts.items()}, "ring_uj": round(ring, 4),
+                "idle_resident_waves_w": base_w, "socket_w": power["socket_w"], "limit_w": power.get("limit_w"),
+                "prices_nj": {k: round(nj(k), 3) for k in ("mfma16", "mfma32", "valu", "trans", "lds", "l2", "hbm", "hbmw") if k in pr},
+                "prices_source": "profiles/r06_energy_ubench.json (scripts/energy_ubench.py: marginal socket energy per operation, 256 workgroups of "
+                                 "four waves; prices at 2.06-2.39 GHz, the launch itself runs at %.2f GHz)" % (power.get("shader_clock_ghz") or 0.0),
+                "counts_per_utterance_sample": {"mfma_16x16x32": mfma, "transcendental_wave_instr": trans, "valu_wave_instr": valu,
+                                                "lds_bytes": lds_b, "weight_stream_bytes": w_b, "hbm_compulsory_bytes": hbm_r + 4, "ring_bytes": 2 * ring_b}}
+    except Exception as ex:
+        return {"error": str(ex)[:200]}
+
+
 def power_reading(e, N, NTOT, B, sptr, seconds=3.0):
     """Socket power while the timed launch runs back to back for `seconds` (outside the timed region): the SMU's gpu_metrics table
     through `rocm-smi --showmetrics`, polled by scripts/clock_probe.py's sampler (~5 polls per second), beside the kernel's own clock
@@ -1031,7 +1081,7 @@ def main():
         tiles = (B + 15) // 16
         kname = kinfo.split(" ")[0]                             # what the engine reports it launches
         chain_mode = "wavenet_chain" in kname
-        bt = 3 if "BT=3" in kname else 2 if "BT=2" in kname else 1
+        bt = 4 if "BT=4" in kname else 3 if "BT=3" in kname else 2 if "BT=2" in kname else 1
         if not args.batch and args.config == "headline" and tiles > ncu:
             assert kname == HEADLINE_KERNELS[bt].replace("RAW=0", "RAW=3" if args.conditioning == "features" else "RAW=0"), kinfo     # the launches the parity tests pin
         # workgroups (weight-stream passes) per sample
@@ -1084,6 +1134,15 @@ def main():
             roofline["frac_at_measured_clock"] = roofline["frac"] * 2.4 / clock_ghz
         if power:
             roofline["power"] = power
+            en = energy_roofline(power, kern_ms, B, N, bt, args.conditioning == "features")
+            if en:
+                roofline["energy"] = en
+            # what binds: with every CU busy the socket sits at its power limit and gives the clock away -- the launch is
+            # bound by joules per utterance-sample, not by the matrix pipe nor by HBM
+            if power.get("limit_w") and power.get("socket_w", 0) >= 0.95 * power["limit_w"]:
+                roofline["bound"] = "power"
+                roofline["bound_evidence"] = ("socket %.0f W of %.0f W with the clock at %.2f GHz (2.4 GHz unconstrained); the MFMA figures below are "
+                                              "kept as the FLOP accounting the harness asks for" % (power["socket_w"], power["limit_w"], power.get("shader_clock_ghz") or 0.0))
         roofline["hbm"]["frac"] = roofline["hbm"]["achieved"] / HBM_PEAK_GBS
         # ... and with the dilation ring, which this design keeps in HBM (read x[t-d], write x[t]: 2 x 2R bytes per layer, utterance and
         # sample): the bytes the kernel actually asks of the memory system (what `traffic` measures), and the roof it is nearest to

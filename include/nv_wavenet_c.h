@@ -53,10 +53,12 @@ nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int m
                        int batch_size, int num_samples, int implementation, int tanh_embed);
 /* The same with an explicit kernel organisation (the last, optional argument of this repo's nvWavenetInfer
  * constructor; 0 = from `implementation` and the batch size like nvw_create):
- *   1 wavenet_wg (1, 2 or 3 tiles of 16 utterances per workgroup by batch size)   2 / 3 / 4 wavenet_wg with exactly 1 / 2 / 3
+ *   1 wavenet_wg (1 to 4 tiles of 16 utterances per workgroup by batch size)   2 / 3 / 4 wavenet_wg with exactly 1 / 2 / 3
  *   (three: fp16, R <= 64; two tiles otherwise)   5 wavenet_chain (multi-CU, resident weights, fewest CUs)
  *   6 wavenet_chain with one layer per CU   7, 8, 9 retired (were wavenet_bcast -- every wave the whole network for its own
- *   tile, weights broadcast through an LDS ring -- and its variants; removed in round 5): refused like any number out of range.
+ *   tile, weights broadcast through an LDS ring -- and its variants; removed in round 5): refused like any number out of range
+ *   10 wavenet_wg with four tiles per workgroup (round 6: fp16, R <= 64, dump-free launches with packed or feature conditioning;
+ *   other launches of such an engine take three).
  * Returns NULL when the shape does not fit a CU in that organisation (the reference's variants print
  * and return false for shapes they do not support, nv_wavenet_singleblock.cuh:273-286). */
 nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, int max_dilation,

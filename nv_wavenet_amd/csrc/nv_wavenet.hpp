@@ -60,7 +60,8 @@ enum nvwOrganisation {
     NVW_ORG_RETIRED7 = 7, // were: wn::wavenet_bcast (every wave its own tile, weights broadcast through an LDS ring; rounds 3-4) and its
     NVW_ORG_RETIRED8 = 8, // variants: measured, never real time anywhere, removed in round 5 (LABNOTES.md) -- refused
     NVW_ORG_RETIRED9 = 9,
-    NVW_ORG_LAST = NVW_ORG_CHAIN1
+    NVW_ORG_WG4 = 10,     // wn::wavenet_wg, four tiles per workgroup (round 6: fp16, R <= 64, dump-free packed / feature conditioning; else three)
+    NVW_ORG_LAST = NVW_ORG_WG4
 };
 
 template <typename T_weight, typename T_data, int R = 64, int S = 128, int A = 256>
@@ -204,12 +205,13 @@ protected:
         hipLaunchKernelGGL((wn::convert_kernel<F16>), dim3(gridFor(n)), dim3(256), 0, 0, dst, d, n);
         gpuErrChk(hipGetLastError());
     }
-    template <int BT> static size_t ldsNeed(int L, int embTables) { return wn::Cfg<F16, R, S, A, BT>::ldsBytes(L, embTables); }
+    // (dump: the kernel variant that can dump holds every layer's running skip-bias sum in LDS, the dump-free one a single row)
+    template <int BT> static size_t ldsNeed(int L, int embTables, bool dump = true) { return wn::Cfg<F16, R, S, A, BT>::ldsBytes(L, embTables, dump); }
     static constexpr size_t kLdsMax = 160 * 1024;
-    template <int BT> bool ldsFits() const { return ldsNeed<BT>(m_numLayers, 0) <= kLdsMax; }
+    template <int BT> bool ldsFits(bool dump = true) const { return ldsNeed<BT>(m_numLayers, 0, dump) <= kLdsMax; }
     // how many embedding tables fit in LDS beside everything else: 2, 1 (current tap) or 0
-    template <int BT> int embTables() const {
-        return ldsNeed<BT>(m_numLayers, 2) <= kLdsMax ? 2 : ldsNeed<BT>(m_numLayers, 1) <= kLdsMax ? 1 : 0;
+    template <int BT> int embTables(bool dump = true) const {
+        return ldsNeed<BT>(m_numLayers, 2, dump) <= kLdsMax ? 2 : ldsNeed<BT>(m_numLayers, 1, dump) <= kLdsMax ? 1 : 0;
     }
     // DUMP = false (no activation dump code at all): every conditioning path of the fp16 engine (the production path); for the fp32
     // engine -- the parity mode, and what the reference's PyTorch entry wavenet_infer() runs -- the packed-conditioning kernels and
@@ -220,11 +222,11 @@ protected:
         const int grid = (tiles + BT - 1) / BT;
         p.embLds = nEmb;
         hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW>), dim3(grid), dim3(CB::THREADS),
-                           ldsNeed<BT>(m_numLayers, nEmb), stream, p);
+                           ldsNeed<BT>(m_numLayers, nEmb, DUMP), stream, p);
         return hipGetLastError() == hipSuccess;
     }
     template <int BT, bool DUMP, int RAW> bool launchE(wn::Params& p, int tiles, hipStream_t stream) {
-        const int nEmb = embTables<BT>();
+        const int nEmb = embTables<BT>(DUMP);
         return nEmb ? launchK<BT, true, DUMP, RAW>(p, tiles, nEmb, stream) : launchK<BT, false, DUMP, RAW>(p, tiles, 0, stream);
     }
     template <int BT, bool DUMP> bool launchD(wn::Params& p, int tiles, hipStream_t stream) {
@@ -242,7 +244,7 @@ protected:
         return launchD<BT, true>(p, tiles, stream);
     }
     template <int BT, bool EMB, bool DUMP, int RAW> void allowLdsK() {
-        const size_t need = ldsNeed<BT>(m_numLayers, EMB ? embTables<BT>() : 0);
+        const size_t need = ldsNeed<BT>(m_numLayers, EMB ? embTables<BT>(DUMP) : 0, DUMP);
         if (need <= kLdsMax)
             gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
@@ -359,8 +361,17 @@ protected:
         if constexpr (WG3) return ldsFits<3>();
         return false;
     }
+    // ... with a four-tile one (round 6): dump-free kernels only -- the folded skip-bias table is what makes room for the fourth tile's
+    // exchange images -- and for the packed / feature conditioning; other launches of such an engine take three tiles per workgroup
+    static constexpr bool WG4 = WG3;
+    bool wg4Fits() const {
+        if constexpr (WG4) return ldsFits<4>(false);
+        return false;
+    }
     int wgTiles(int tiles) const {
-        const bool three = m_org == NVW_ORG_WG3 || (m_org == NVW_ORG_WG && tiles > 2 * m_numCUs);
+        const bool four = m_org == NVW_ORG_WG4 || (m_org == NVW_ORG_WG && tiles > WN_WG4_FROM * m_numCUs);
+        if (four && wg4Fits() && wg3Fits()) return 4;
+        const bool three = four || m_org == NVW_ORG_WG3 || (m_org == NVW_ORG_WG && tiles > 2 * m_numCUs);
         if (three && wg3Fits()) return 3;
         const bool two = three || m_org == NVW_ORG_WG2 || (m_org == NVW_ORG_WG && tiles > m_numCUs);
         if constexpr (WG2) return (two && ldsFits<2>()) ? 2 : 1;
@@ -402,7 +413,8 @@ public:
         // exactly the tiles of the batch
         {
             const int tiles = (batchSize + 15) / 16;
-            const int group = isChain() ? 1 : wgTiles(tiles);
+            int group = isChain() ? 1 : wgTiles(tiles);
+            if (group == 4) group = 12;      // (launches that dump or read the conditioning in place take three tiles per workgroup)
             m_tiles = (tiles + group - 1) / group * group;
         }
 
@@ -480,6 +492,14 @@ public:
             if (!isChain()) {
                 if constexpr (WG2) allowLds<2>();
                 if constexpr (WG3) allowLds<3>();
+                if constexpr (WG4) {
+                    if (wg4Fits()) {
+                        allowLdsK<4, false, false, 0>();
+                        allowLdsK<4, true, false, 0>();
+                        allowLdsK<4, false, false, 3>();
+                        allowLdsK<4, true, false, 3>();
+                    }
+                }
             }
         }
         gpuErrChk(hipDeviceSynchronize());
@@ -977,23 +997,28 @@ public:
                      m_chainStages * chains, CC::ldsBytes());
             return;
         }
-        const int bt = wgTiles(tiles);
-        int nEmb = embTables<1>();
-        size_t lds = ldsNeed<1>(m_numLayers, nEmb);
+        const int raw = m_featPtr ? 3 : m_condRaw ? m_condRawKind : 0;
+        const int bt = launchTiles(tiles, dump, raw);
+        int nEmb = embTables<1>(dump);
+        size_t lds = ldsNeed<1>(m_numLayers, nEmb, dump);
         if constexpr (WG2) {
             if (bt == 2) {
-                nEmb = embTables<2>();
-                lds = ldsNeed<2>(m_numLayers, nEmb);
+                nEmb = embTables<2>(dump);
+                lds = ldsNeed<2>(m_numLayers, nEmb, dump);
             }
         }
         if constexpr (WG3) {
             if (bt == 3) {
-                nEmb = embTables<3>();
-                lds = ldsNeed<3>(m_numLayers, nEmb);
+                nEmb = embTables<3>(dump);
+                lds = ldsNeed<3>(m_numLayers, nEmb, dump);
+            }
+            if (bt == 4) {
+                nEmb = embTables<4>(dump);
+                lds = ldsNeed<4>(m_numLayers, nEmb, dump);
             }
         }
         snprintf(buf, n, "wn::wavenet_wg<%s,%d,%d,%d,BT=%d,EMBLDS=%d,DUMP=%d,RAW=%d> tiles/wg=%d wgs=%d lds=%zu",
-                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, m_featPtr ? 3 : m_condRaw ? m_condRawKind : 0, bt, (tiles + bt - 1) / bt, lds);
+                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, raw, bt, (tiles + bt - 1) / bt, lds);
     }
 
     // ---- debug getters: last generated sample's activations, reference layouts --------------
@@ -1105,7 +1130,8 @@ public:
             // padding tiles beyond the batch included (a later, larger batch must find those slots zero as well)
             int touched = (batch_size + 15) / 16;
             if (!(isChain() && !m_featPtr)) {
-                const int bt = wgTiles(touched);
+                int bt = wgTiles(touched);
+                if (bt == 4) bt = 12;      // (three or four tiles per workgroup by launch: both roundings)
                 touched = (touched + bt - 1) / bt * bt;
             }
             if (touched > m_tiles) touched = m_tiles;
@@ -1267,9 +1293,18 @@ protected:
         gpuErrChk(hipMemcpy(&s, m_chainStatus + i, sizeof(unsigned), hipMemcpyDeviceToHost));
         return s;
     }
-    // wavenet_wg by batch size: one, two or three tiles per workgroup
-    bool launchWg(wn::Params& p, int tiles, hipStream_t stream) {
+    // tiles per workgroup of THIS launch: the four-tile kernels exist dump-free and for the packed (0) / feature (3) conditioning only
+    int launchTiles(int tiles, bool dump, int raw) const {
         const int bt = wgTiles(tiles);
+        return (bt == 4 && (dump || (raw != 0 && raw != 3))) ? 3 : bt;
+    }
+    // wavenet_wg by batch size: one to four tiles per workgroup
+    bool launchWg(wn::Params& p, int tiles, hipStream_t stream) {
+        const int bt = launchTiles(tiles, p.dump != 0, p.condRawKind);
+        if (bt == 4) {
+            if constexpr (WG4) return p.condRawKind == 3 ? launchE<4, false, 3>(p, tiles, stream) : launchE<4, false, 0>(p, tiles, stream);
+            return false;
+        }
         if (bt == 3) {
             if constexpr (WG3) return launch<3>(p, tiles, stream);
             return false;
@@ -1355,9 +1390,9 @@ protected:
     // wavenet_wg<BT = 1> for tiles [tile0, tile0 + ntiles), gated on Params::gate
     template <bool EMB> bool launchGated(wn::Params& q, int tile0, int ntiles, int nEmb, hipStream_t stream) {
         q.tileBase = tile0;
-        const size_t lds = ldsNeed<1>(m_numLayers, nEmb);
         const int kind = q.condRawKind;
         const bool dump = q.dump != 0 || (!F16 && kind != 0);      // (see launch(): the fp32 dump-free kernel is the packed one)
+        const size_t lds = ldsNeed<1>(m_numLayers, nEmb, dump);
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(ntiles), dim3(C::THREADS), lds, stream, q);
             return hipGetLastError() == hipSuccess;

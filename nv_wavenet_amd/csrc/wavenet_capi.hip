@@ -52,7 +52,7 @@ nvw_engine* nvw_create_ex(int R, int S, int A, int precision, int num_layers, in
         fprintf(stderr, "nvw_create: implementation %d out of range 0..4\n", implementation);
         return NULL;
     }
-    if (organisation < NVW_ORG_AUTO || organisation > NVW_ORG_LAST) {
+    if (organisation < NVW_ORG_AUTO || organisation > NVW_ORG_LAST || (organisation >= NVW_ORG_RETIRED7 && organisation <= NVW_ORG_RETIRED9)) {
         fprintf(stderr, "nvw_create: organisation %d out of range 0..%d\n", organisation, (int)NVW_ORG_LAST);
         return NULL;
     }

@@ -503,19 +503,9 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
                     acc[li][2 * i] = *(const floatx4*)(bl + (w + NW * i) * 16 + g * 4);
                     acc[li][2 * i + 1] = *(const floatx4*)(bl + (w + NW * i + RT) * 16 + g * 4);
                 }
-                // + conditioning (fp16: a B-layout fragment added by the matrix core through a 0/1 selection matrix)
-                if constexpr (F16) {
+                // + conditioning (a B-layout fragment = the D layout of TPF result tiles: wn::cond_add, shared with wavenet_wg)
 #pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int tt = 0; tt < P::TPF; tt++)
-                            acc[li][k * P::TPF + tt] = mma(selA[tt], cd[0][k], acc[li][k * P::TPF + tt]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int e = 0; e < P::EPL; e++) acc[li][k * P::TPF + (e >> 2)][e & 3] += (float)cd[0][k][e];
-                }
+                for (int k = 0; k < C::COND_FR; k++) cond_add<F16>(&acc[li][k * P::TPF], cd[0][k], selA);
                 const int d = dl[li].d;
                 const bool havePrev = t >= d;
                 frag xp[KF_R];

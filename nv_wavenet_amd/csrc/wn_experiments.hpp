@@ -21,6 +21,12 @@
 #ifndef WN_HEADREGS3
 #define WN_HEADREGS3 0       // ... three tiles per workgroup: the whole head is streamed
 #endif
+#ifndef WN_COND_VALU
+#define WN_COND_VALU 1       // packed / in-place conditioning added by v_fma_mix_f32 (1, round 6) or through 0/1 selection MFMAs (0, rounds 1-5)
+#endif
+#ifndef WN_WG4_FROM
+#define WN_WG4_FROM 3        // AUTO: four tiles per workgroup for batches beyond this many tiles per CU (3: beyond the three-tile capacity)
+#endif
 #ifndef WN_TAKE_G
 #define WN_TAKE_G 1          // wavenet_wg: weight fragments waited for together (take_group); > 1 measured slower
 #endif

@@ -202,9 +202,13 @@ struct Cfg {
     static constexpr int OFF_XP = OFF_Y + YBUF;
     static constexpr int LDS_FIXED = OFF_XP + XPBUF;
     // + optionally both embedding tables (T_data) behind the bias table
-    static size_t ldsBytes(int L, int embTables) {      // embTables: 0, 1 (current tap only) or 2
-        return (size_t)LDS_FIXED + ((size_t)L * BIAS_L + 2 * A) * sizeof(float) +
-               (size_t)embTables * A * R * sizeof(typename P::elem);
+    // Bias table in LDS.  Kernels that can dump hold the model's table as it is, [L][Bh | Bres | Bskip] + the head's, the skip rows turned
+    // into running sums (the per-layer skipOut dump needs every one of them).  Dump-free kernels (round 6) only ever add the LAST running
+    // sum -- at the head --, so they hold [L][Bh | Bres], ONE row of S skip-bias sums, then the head's: S * (L - 1) floats less (C3: 19 KiB).
+    static constexpr int BIAS_LN = 3 * R;                  // per-layer stride of the dump-free table
+    __host__ __device__ static constexpr int biasFloats(int L, bool dump) { return (dump ? L * BIAS_L : L * BIAS_LN + S) + 2 * A; }
+    static size_t ldsBytes(int L, int embTables, bool dump = true) {      // embTables: 0, 1 (current tap only) or 2
+        return (size_t)LDS_FIXED + (size_t)biasFloats(L, dump) * sizeof(float) + (size_t)embTables * A * R * sizeof(typename P::elem);
     }
     // per-wave stream in memory: [L][FLW] layers | [FHW] head
     __host__ __device__ static size_t headOffsetFrags(int L) { return (size_t)L * FLW; }
@@ -793,6 +797,47 @@ template <bool F16, int RAW, int CR> WN_DEV typename Prec<F16>::frag cond_frag(c
     }
 }
 
+// acc += the conditioning fragment.  A fragment in B layout IS the D layout of TPF result tiles (lane (g,j), element e: row 4g + (e&3)
+// of tile e>>2, utterance j), so the add is element by element in the lane that holds both.
+// fp16, WN_COND_VALU (round 6): one v_fma_mix_f32 per value -- acc = fp16 value * 1.0 + acc, the conversion folded into the add -- 8 VALU
+// instructions per fragment.  Rounds 1-5 added it on the matrix core through a 0/1 selection matrix (2 MFMAs per fragment: 8.6 % of a
+// sample's MFMAs, each a 16x16x32 product of which one term per output is not zero): the same sum -- one exact product, one rounding --
+// at 8 k multiply-adds of matrix-core energy per 64 useful additions.  Both forms are kept behind the switch for the A/B.
+WN_DEV float fma_mix_lo(unsigned h2, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(acc));
+    return d;
+}
+WN_DEV float fma_mix_hi(unsigned h2, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(acc));
+    return d;
+}
+// a[0 .. TPF-1]: the TPF consecutive result tiles the fragment covers
+template <bool F16> WN_DEV void cond_add(floatx4* a, typename Prec<F16>::frag c, const typename Prec<F16>::frag* selA) {
+    if constexpr (F16) {
+#if WN_COND_VALU
+        (void)selA;
+        const uintx4 q = __builtin_bit_cast(uintx4, c);
+        a[0][0] = fma_mix_lo(q[0], a[0][0]);
+        a[0][1] = fma_mix_hi(q[0], a[0][1]);
+        a[0][2] = fma_mix_lo(q[1], a[0][2]);
+        a[0][3] = fma_mix_hi(q[1], a[0][3]);
+        a[1][0] = fma_mix_lo(q[2], a[1][0]);
+        a[1][1] = fma_mix_hi(q[2], a[1][1]);
+        a[1][2] = fma_mix_lo(q[3], a[1][2]);
+        a[1][3] = fma_mix_hi(q[3], a[1][3]);
+#else
+#pragma unroll
+        for (int tt = 0; tt < Prec<F16>::TPF; tt++) a[tt] = mma(selA[tt], c, a[tt]);
+#endif
+    } else {
+        (void)selA;
+#pragma unroll
+        for (int e = 0; e < Prec<F16>::EPL; e++) a[e >> 2][e & 3] += (float)c[e];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // the engine kernel: one workgroup generates `count` samples for BT tiles of 16 utterances
 // ------------------------------------------------------------------------------------------
@@ -861,22 +906,33 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     const int su = tid / C::LPU, sq = tid % C::LPU;
 
     // ---- biases -> LDS ----------------------------------------------------------------------
-    {
-        const int nb = L * C::BIAS_L + 2 * A;
-        for (int i = tid; i < nb; i += C::THREADS) biasLds[i] = p.bias[i];
-    }
-    const float* const headBias = biasLds + L * C::BIAS_L;
     // The skip accumulator is only touched by MFMAs inside the layer loop: the per-layer skip biases
     // are turned into running sums here (slot of layer l := Bskip_0 + ... + Bskip_l, added in layer
     // order like the oracle does) and added once, at the head and in the per-layer dumps.
-    __syncthreads();
-    for (int s0 = tid; s0 < S; s0 += C::THREADS) {
-        float run = biasLds[3 * R + s0];
-        for (int l = 1; l < L; l++) {
-            run += biasLds[l * C::BIAS_L + 3 * R + s0];
-            biasLds[l * C::BIAS_L + 3 * R + s0] = run;
+    // DUMP kernels keep every running sum (the skipOut dump of layer l needs sum l); dump-free kernels only the last (Cfg::biasFloats).
+    constexpr int BLS = DUMP ? C::BIAS_L : C::BIAS_LN;            // per-layer stride of the table in LDS
+    if constexpr (DUMP) {
+        const int nb = L * C::BIAS_L + 2 * A;
+        for (int i = tid; i < nb; i += C::THREADS) biasLds[i] = p.bias[i];
+        __syncthreads();
+        for (int s0 = tid; s0 < S; s0 += C::THREADS) {
+            float run = biasLds[3 * R + s0];
+            for (int l = 1; l < L; l++) {
+                run += biasLds[l * C::BIAS_L + 3 * R + s0];
+                biasLds[l * C::BIAS_L + 3 * R + s0] = run;
+            }
+        }
+    } else {
+        for (int i = tid; i < L * C::BIAS_LN; i += C::THREADS) biasLds[i] = p.bias[(i / C::BIAS_LN) * C::BIAS_L + i % C::BIAS_LN];
+        for (int i = tid; i < 2 * A; i += C::THREADS) biasLds[L * C::BIAS_LN + S + i] = p.bias[L * C::BIAS_L + i];
+        for (int s0 = tid; s0 < S; s0 += C::THREADS) {
+            float run = p.bias[3 * R + s0];
+            for (int l = 1; l < L; l++) run += p.bias[l * C::BIAS_L + 3 * R + s0];      // (the same additions in the same order)
+            biasLds[L * C::BIAS_LN + s0] = run;
         }
     }
+    const float* const skipBiasSum = DUMP ? biasLds + (L - 1) * C::BIAS_L + 3 * R : biasLds + L * C::BIAS_LN;      // Bskip_0 + ... + Bskip_{L-1}
+    const float* const headBias = biasLds + (C::biasFloats(L, DUMP) - 2 * A);
 
     const unsigned laneOff = (unsigned)lane * 16u;
     // wave-uniform byte bases (SGPRs); per-lane part is laneOff
@@ -887,7 +943,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     if constexpr (EMBLDS) {
         // p.embLds tables fit in LDS: the current tap's (its gather follows every pick, on the
         // critical path) and, if there is room, the older tap's (gathered one sample early)
-        elem* const embLds = (elem*)(biasLds + L * C::BIAS_L + 2 * A);
+        elem* const embLds = (elem*)(biasLds + C::biasFloats(L, DUMP));
         const floatx4* s0 = (const floatx4*)p.embCur;
         const floatx4* s1 = (const floatx4*)p.embPrev;
         constexpr int CH = (int)(A * R * sizeof(elem) / 16);
@@ -1095,21 +1151,11 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
                 for (int k = 0; k < KFC; k++) asm volatile("" ::"v"(cfNext[bt][k]));
-        } else if constexpr (F16) {
-#pragma unroll
-            for (int bt = 0; bt < BT; bt++)
-#pragma unroll
-                for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                    for (int tt = 0; tt < P::TPF; tt++)
-                        acc[bt][k * P::TPF + tt] = mma(selA[tt], cond_frag<F16, RAW>(cdA[bt], k), acc[bt][k * P::TPF + tt]);
         } else {
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
-                for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                    for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cdA[bt][k][e];
+                for (int k = 0; k < C::COND_FR; k++) cond_add<F16>(&acc[bt][k * P::TPF], cond_frag<F16, RAW>(cdA[bt], k), selA);
         }
         gemm_direct<F16, BT, 2 * HTW, KF_R>(wbase + C::streamPos(0, C::O_PREV, L) * 1024, laneOff, acc, xp);
     }
@@ -1185,9 +1231,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             // only a one-deep ring, read garbage there -- found by the O(1)-recipe parity test of round 3)
             constexpr int PB = SKIP ? 0 : FLW;
             const int wl = SKIP ? (l - 1) * FLW : 0;
-            const float* bl = biasLds + l * C::BIAS_L;
+            const float* bl = biasLds + l * BLS;
             const int lN = l + 1 < L ? l + 1 : 0;
-            const float* blN = biasLds + lN * C::BIAS_L;
+            const float* blN = biasLds + lN * BLS;
             const int d = dl.d;
 
             // current tap on top of bias + conditioning + dilated tap (xb: x as B fragments, requested behind the
@@ -1399,21 +1445,11 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             // conversions + 8 adds per fragment)
             if constexpr (FEAT) {
                 // (computed under the gate above)
-            } else if constexpr (F16) {
-#pragma unroll
-                for (int bt = 0; bt < BT; bt++)
-#pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int tt = 0; tt < P::TPF; tt++)
-                            acc[bt][k * P::TPF + tt] = mma(selA[tt], cond_frag<F16, RAW>(cdN[bt], k), acc[bt][k * P::TPF + tt]);
             } else {
 #pragma unroll
                 for (int bt = 0; bt < BT; bt++)
 #pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++)
-#pragma unroll
-                        for (int e = 0; e < P::EPL; e++) acc[bt][k * P::TPF + (e >> 2)][e & 3] += (float)cdN[bt][k][e];
+                    for (int k = 0; k < C::COND_FR; k++) cond_add<F16>(&acc[bt][k * P::TPF], cond_frag<F16, RAW>(cdN[bt], k), selA);
             }
             if (dumpNow) {
 #pragma unroll
@@ -1480,8 +1516,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         for (int bt = 0; bt < BT; bt++)
 #pragma unroll
             for (int i = 0; i < STW; i++) {
-                floatx4 v = skip[bt][i] +
-                            *(const floatx4*)(biasLds + (L - 1) * C::BIAS_L + 3 * R + (w + NW * i) * 16 + g * 4);
+                floatx4 v = skip[bt][i] + *(const floatx4*)(skipBiasSum + (w + NW * i) * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.f);
                 lds_put_tile<F16>(skbuf + bt * KF_S * 1024, w + NW * i, lane, v);
@@ -1537,6 +1572,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     selv[0] = dpp_f<0x150>(mine);                       // row_newbcast:0
                     if constexpr (BT > 1) selv[1] = dpp_f<0x151>(mine);
                     if constexpr (BT > 2) selv[2] = dpp_f<0x152>(mine);
+                    if constexpr (BT > 3) selv[3] = dpp_f<0x153>(mine);
                 } else {
 #pragma unroll
                     for (int bt = 0; bt < BT; bt++) {

@@ -31,7 +31,8 @@ class Org:
     CHAIN = 5       # wn::wavenet_chain: multi-CU, weights resident, fewest CUs
     CHAIN1 = 6      # wn::wavenet_chain, one layer per CU
     # (7, 8, 9 were wn::wavenet_bcast and its variants, removed in round 5: refused by nvw_create_ex)
-    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6}
+    WG4 = 10        # four tiles per workgroup (round 6: fp16, R <= 64, dump-free launches; else three)
+    BY_NAME = {None: 0, "auto": 0, "wg": 1, "wg1": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6, "wg4": 10}
 
 
 def supported_configs():
@@ -63,8 +64,8 @@ class WavenetEngine:
         self.precision = precision
         if isinstance(organisation, str) or organisation is None:
             organisation = Org.BY_NAME[organisation]
-        if organisation not in range(max(v for v in Org.BY_NAME.values()) + 1):
-            raise ValueError("organisation must be 0..%d" % max(v for v in Org.BY_NAME.values()))
+        if organisation not in set(Org.BY_NAME.values()):
+            raise ValueError("organisation must be one of %s" % sorted(set(Org.BY_NAME.values())))
         self._h = lib.nvw_create_ex(R, S, A, precision, numLayers, maxDilation, batchSize, numSamples, impl,
                                     1 if tanhEmbed else 0, organisation)
         if not self._h:

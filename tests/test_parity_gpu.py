@@ -643,8 +643,8 @@ def test_benchmarked_path_exactly(tiles_per_cu):
     (packConditioning), run_range(0, 640) and then run_range(640, n): what is compared is nv_wavenet_test.cu:259-304's,
     what the selectors replace is wavenet_infer.cu:92-94's rand() table.  tiles_per_cu = 0: 16 utterances, held to the fp32
     oracle fed philox_selectors(seed) and the same conditioning by util.fp16_bars (the last launch with the dump on; the
-    dump-free kernels must generate the same samples); tiles_per_cu = 3: the headline batch (3 x 16 x CUs utterances, the
-    three-tile kernel bench.py asserts), every utterance bit-identical to its 16-utterance original."""
+    dump-free kernels must generate the same samples); tiles_per_cu = 3 / 4: 3 / 4 x 16 x CUs utterances on the three- / four-tile
+    kernel bench.py asserts, every utterance bit-identical to its 16-utterance original."""
     import torch
     import bench
     from nv_wavenet_amd import WavenetEngine
@@ -707,16 +707,20 @@ def test_benchmarked_path_exactly(tiles_per_cu):
         y48 = sequence(3 * s.B, util.MODE_ORG["wg"])
         assert np.array_equal(y48[:s.B], y16)
         assert not np.array_equal(y48[s.B:2 * s.B], y16), "utterances 16.. drew utterance 0..'s selectors"
-        for mode in ("wg3",):
+        for mode in ("wg3", "wg4"):
             assert np.array_equal(sequence(3 * s.B, util.MODE_ORG[mode]), y48), "%s differs from the one-tile kernel on the benchmarked sequence" % mode
+        # ... and the four-tile kernel (round 6) with all four of its tiles in use
+        y64 = sequence(4 * s.B, util.MODE_ORG["wg"])
+        assert np.array_equal(y64[:3 * s.B], y48)
+        assert np.array_equal(sequence(4 * s.B, util.MODE_ORG["wg4"], bench.HEADLINE_KERNELS[4]), y64), "wg4 differs from the one-tile kernel"
         return
     # the headline batch (the engine's own choice: three tiles per workgroup, the kernel bench.py asserts): its first 1024
     # utterances against the one-tile kernel run on 1024 utterances, whose first 16 are the oracle-held ones of the other case
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     B = tiles_per_cu * 16 * ncu
-    # (four and eight tiles per CU: whole rounds of three-tile wavenet_wg workgroups -- the launch shapes of bench.py's
-    #  `oversubscribed` entry)
-    y = sequence(B, 0, bench.HEADLINE_KERNELS[3])
+    # (four tiles per CU: the four-tile kernel of round 6, one workgroup per CU; eight: two rounds of it -- the launch shapes of
+    #  bench.py's real-time probe at 16 384 utterances and of its `oversubscribed` entry)
+    y = sequence(B, 0, bench.HEADLINE_KERNELS[min(tiles_per_cu, 4)])
     y1k = sequence(1024, util.MODE_ORG["wg"])
     assert np.array_equal(y[:1024], y1k), "the headline batch differs from the one-tile kernel on the benchmarked sequence"
     assert np.array_equal(y1k[:s.B], sequence(s.B, util.MODE_ORG["wg"]))

@@ -7,7 +7,7 @@ from oracle import oracle as O
 import cases
 
 # test "mode" names -> nvwOrganisation (wg = exactly one tile per workgroup, the latency kernel as first built)
-MODE_ORG = {None: 0, "auto": 0, "wg": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6}
+MODE_ORG = {None: 0, "auto": 0, "wg": 2, "wg2": 3, "wg3": 4, "chain": 5, "chain1": 6, "wg4": 10}
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
