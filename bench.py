@@ -72,9 +72,9 @@ HEAD = C3                                     # the shape the headline metric is
 R, S, A, L, MAXD = HEAD.R, HEAD.S, HEAD.A, HEAD.L, HEAD.maxD
 # the device code the engine launches for the headline point (asserted against nvw_kernel_info, and pinned
 # by tests/test_parity_gpu.py::test_benchmarked_launch_*: the timed kernel is the parity-tested one)
-HEADLINE_KERNELS = {2: "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=2,DUMP=0,RAW=0>",     # by tiles per workgroup
-                    3: "wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0,RAW=0>",
-                    4: "wn::wavenet_wg<fp16,64,256,256,BT=4,EMBLDS=0,DUMP=0,RAW=0>"}
+HEADLINE_KERNELS = {2: "wn::wavenet_wg<fp16,64,256,256,BT=2,EMBLDS=1,DUMP=0,RAW=0,LR=1>",     # by tiles per workgroup
+                    3: "wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0,RAW=0,LR=1>",
+                    4: "wn::wavenet_wg<fp16,64,256,256,BT=4,EMBLDS=0,DUMP=0,RAW=0,LR=1>"}
 HEADLINE_KERNEL = HEADLINE_KERNELS[2]
 
 

@@ -42,7 +42,8 @@ typedef void (*nvw_consume_fn)(int* yOut, int init_sample, int count, void* user
  * organisation codes of nvw_create_ex, which were renumbered once (round 3) and lost code 9 in round 4: a caller built against
  * another revision should check this instead of finding a different kernel behind a number.  5 = round 5 (the
  * feature-conditioning entry points below); 6 = this header (round 6: nvw_get_features returns int; nvw_upsample_features,
- * nvw_generate_stream and nvw_get_features check their ranges and refuse with 0 instead of reaching the class's asserts). */
+ * nvw_generate_stream and nvw_get_features check their ranges and refuse with 0 instead of reaching the class's asserts;
+ * organisation 10; nvw_set_ring_in_lds). */
 #define NVW_ABI_VERSION 6
 int nvw_abi_version(void);
 int nvw_supported(int R, int S, int A, int precision);
@@ -57,7 +58,7 @@ nvw_engine* nvw_create(int R, int S, int A, int precision, int num_layers, int m
  *   (three: fp16, R <= 64; two tiles otherwise)   5 wavenet_chain (multi-CU, resident weights, fewest CUs)
  *   6 wavenet_chain with one layer per CU   7, 8, 9 retired (were wavenet_bcast -- every wave the whole network for its own
  *   tile, weights broadcast through an LDS ring -- and its variants; removed in round 5): refused like any number out of range
- *   10 wavenet_wg with four tiles per workgroup (round 6: fp16, R <= 64, dump-free launches with packed or feature conditioning;
+ *   10 wavenet_wg with four tiles per workgroup (round 6: fp16, R <= 64, dump-free launches with packed conditioning;
  *   other launches of such an engine take three).
  * Returns NULL when the shape does not fit a CU in that organisation (the reference's variants print
  * and return false for shapes they do not support, nv_wavenet_singleblock.cuh:273-286). */
@@ -191,6 +192,11 @@ void nvw_set_chain_timeout_ms(nvw_engine* e, double ms);
  * constant-rate wall-clock counters at its start and end; nvw_last_launch_clock_ghz returns shader ticks per wall second of the
  * latest launch, i.e. the clock the chip granted it under its power budget (0 when nothing was probed); synchronises the device. */
 void nvw_set_clock_probe(nvw_engine* e, int on);
+/* The dilation ring on chip (round 6; the reference stages x[t-d] through shared memory out of a global ring, nv_wavenet.cuh:96-127,
+ * 334-335): single-workgroup launches keep the ring slots of the layers with the shortest dilations in the LDS their tables leave
+ * free, loaded from / spilled to the HBM ring at the launch's ends (1-KiB rows).  mode >= 0 (default): as many layers as fit -- a model
+ * whose whole ring fits has no ring traffic to HBM during the launch; -1: never.  Same samples either way. */
+void nvw_set_ring_in_lds(nvw_engine* e, int mode);
 double nvw_last_launch_clock_ghz(nvw_engine* e);
 /* Samples [init_sample, init_sample + count) of a num_samples-long utterance, asynchronously on `stream`
  * (one chunk of run_chunks, for hosts that drive the chunks themselves); nvw_reset_history starts a new

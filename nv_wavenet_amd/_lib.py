@@ -61,6 +61,7 @@ SIGNATURES = {
     "nvw_chain_last_timeout": (C.c_uint, [C.c_void_p]),
     "nvw_set_chain_timeout_ms": (None, [C.c_void_p, C.c_double]),
     "nvw_set_clock_probe": (None, [C.c_void_p, C.c_int]),
+    "nvw_set_ring_in_lds": (None, [C.c_void_p, C.c_int]),
     "nvw_last_launch_clock_ghz": (C.c_double, [C.c_void_p]),
     "nvw_run_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "nvw_reset_history": (None, [C.c_void_p, C.c_void_p]),

@@ -42,6 +42,7 @@ struct nvw_engine {
     virtual unsigned chainLastTimeout() = 0;
     virtual void setChainTimeoutMs(double) = 0;
     virtual void setClockProbe(bool) = 0;
+    virtual void setRingInLds(int) = 0;
     virtual double lastLaunchClockGHz() = 0;
     virtual int precisionBits() = 0;
     virtual int maxSamples() = 0;
@@ -105,6 +106,7 @@ struct EngineImpl : nvw_engine {
     unsigned chainLastTimeout() override { return eng.chainLastTimeout(); }
     void setChainTimeoutMs(double ms) override { eng.setChainTimeoutMs(ms); }
     void setClockProbe(bool on) override { eng.setClockProbe(on); }
+    void setRingInLds(int mode) override { eng.setRingInLds(mode); }
     double lastLaunchClockGHz() override { return eng.lastLaunchClockGHz(); }
     int precisionBits() override { return std::is_same<Td, float>::value ? 32 : 16; }
     int maxSamples() override { return cap; }

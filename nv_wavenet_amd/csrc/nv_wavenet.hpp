@@ -60,7 +60,7 @@ enum nvwOrganisation {
     NVW_ORG_RETIRED7 = 7, // were: wn::wavenet_bcast (every wave its own tile, weights broadcast through an LDS ring; rounds 3-4) and its
     NVW_ORG_RETIRED8 = 8, // variants: measured, never real time anywhere, removed in round 5 (LABNOTES.md) -- refused
     NVW_ORG_RETIRED9 = 9,
-    NVW_ORG_WG4 = 10,     // wn::wavenet_wg, four tiles per workgroup (round 6: fp16, R <= 64, dump-free packed / feature conditioning; else three)
+    NVW_ORG_WG4 = 10,     // wn::wavenet_wg, four tiles per workgroup (round 6: fp16, R <= 64, dump-free launches with packed conditioning; else three)
     NVW_ORG_LAST = NVW_ORG_WG4
 };
 
@@ -93,6 +93,7 @@ protected:
     int m_num_samples_per_chunk;
     int m_ringSlots;
     int m_ringDirtyTiles;         // leading tiles whose rings launches have written since they were last zero
+    int m_ringLdsMode;            // ring slots of the short dilations in LDS during wavenet_wg launches: 0 as many as fit (default), -1 never
     int m_lastStride;    // row stride of m_yOut in the latest launch (= its num_samples)
 
     elem* m_wblob;      // packed weight fragments: L layers then the head
@@ -217,16 +218,81 @@ protected:
     // engine -- the parity mode, and what the reference's PyTorch entry wavenet_infer() runs -- the packed-conditioning kernels and
     // the chain (round 6: that entry has no getter that could read a dump, pytorch/wavenet_infer.h:33-58); fp32 launches that read
     // the conditioning in place or compute it from features carry the dump code whether asked or not
+    // dilation schedule (nv_wavenet.cuh:99,110-111) as a table in the kernel arguments: dilation and first ring slot
+    void fillSchedule(wn::Params& p) const {
+        int d = 1, off = 0;
+        for (int l = 0; l < m_numLayers; l++) {
+            p.dil[l].d = d;
+            p.dil[l].off = off;
+            p.dil[l].lds = 0;
+            off += d;
+            d <<= 1;
+            if (d > m_maxDilation) d = 1;
+        }
+        p.dil[m_numLayers] = p.dil[0];
+        p.dil[m_numLayers + 1] = p.dil[1];
+    }
+    // The ring slots of the short dilations in LDS (round 6): the largest dilation D (a power of two) whose layers' slots -- sum of d
+    // over the layers with d <= D, BT x R/32 KiB each -- fit beside everything else; 0: none.  Sets p.ldsRingD and the LDS slot numbers
+    // of the schedule table; returns the bytes to add to the launch's dynamic LDS.
+    template <int BT> size_t placeLdsRing(wn::Params& p, size_t need) const {
+        using CB = wn::Cfg<F16, R, S, A, BT>;
+        int D = 0;
+        for (int d = 1; d <= m_maxDilation && d <= WN_LDS_RING_MAXD; d <<= 1)
+            if (need + (size_t)CB::ldsRingSlots(m_numLayers, m_maxDilation, d) * CB::RING_SLOT <= kLdsMax) D = d;
+        p.ldsRingD = D;
+        int slot = 0;
+        for (int l = 0; l < m_numLayers; l++) {
+            p.dil[l].lds = slot;
+            if (p.dil[l].d <= D) slot += p.dil[l].d;
+        }
+        p.dil[m_numLayers] = p.dil[0];
+        p.dil[m_numLayers + 1] = p.dil[1];
+        return (size_t)slot * CB::RING_SLOT;
+    }
+    // ... and whether a launch uses them (the LR instantiations of wavenet_wg: dump-free, packed or -- fp16 -- feature conditioning).
+    // m_ringLdsMode >= 0 (default): as many of the short dilations as fit; -1: never.  Measured at C3 (LABNOTES round 6, us per sample
+    // with / without): one tile per workgroup, d <= 4 on chip, 21.1 / 21.7; two tiles, d <= 2 in the place of the older tap's
+    // embedding table, 28.4 / 29.2; three tiles, d <= 1, 37.3 / 37.4; four tiles, d <= 1, 43.6 / 44.2.
+    static constexpr bool lrBuilt(bool dump, int raw) { return !dump && (raw == 0 || (raw == 3 && F16)); }
+    template <int BT> size_t ringPlan(wn::Params& p, size_t need, bool dump, int raw) const {
+        p.ldsRingD = 0;
+        if (!lrBuilt(dump, raw) || m_ringLdsMode < 0) return 0;
+        wn::Params q = p;
+        const size_t bytes = placeLdsRing<BT>(q, need);
+        if (q.ldsRingD <= 0) return 0;
+        p = q;
+        return bytes;
+    }
     template <int BT, bool EMB, bool DUMP, int RAW> bool launchK(wn::Params& p, int tiles, int nEmb, hipStream_t stream) {
         using CB = wn::Cfg<F16, R, S, A, BT>;
         const int grid = (tiles + BT - 1) / BT;
         p.embLds = nEmb;
-        hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW>), dim3(grid), dim3(CB::THREADS),
-                           ldsNeed<BT>(m_numLayers, nEmb, DUMP), stream, p);
+        const size_t need = ldsNeed<BT>(m_numLayers, nEmb, DUMP);
+        if constexpr (lrBuilt(DUMP, RAW)) {
+            const size_t ringBytes = ringPlan<BT>(p, need, DUMP, RAW);
+            if (ringBytes > 0) {
+                hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW, true>), dim3(grid), dim3(CB::THREADS), need + ringBytes, stream, p);
+                return hipGetLastError() == hipSuccess;
+            }
+        }
+        p.ldsRingD = 0;
+        hipLaunchKernelGGL((wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW>), dim3(grid), dim3(CB::THREADS), need, stream, p);
         return hipGetLastError() == hipSuccess;
     }
+    // embedding tables of a launch in LDS: as many as fit; a launch whose two tables leave no room for a single ring slot gives up the
+    // OLDER tap's table for ring slots (its gather is one sample early, off the dependent chain; C3 at two tiles: 28.4 against 29.2 us)
+    template <int BT> int planEmb(bool dump, int raw) const {
+        int nEmb = embTables<BT>(dump);
+        if (nEmb == 2 && m_ringLdsMode >= 0 && lrBuilt(dump, raw)) {
+            wn::Params q;
+            fillSchedule(q);
+            if (placeLdsRing<BT>(q, ldsNeed<BT>(m_numLayers, 2, dump)) == 0) nEmb = 1;
+        }
+        return nEmb;
+    }
     template <int BT, bool DUMP, int RAW> bool launchE(wn::Params& p, int tiles, hipStream_t stream) {
-        const int nEmb = embTables<BT>(DUMP);
+        const int nEmb = planEmb<BT>(DUMP, RAW);
         return nEmb ? launchK<BT, true, DUMP, RAW>(p, tiles, nEmb, stream) : launchK<BT, false, DUMP, RAW>(p, tiles, 0, stream);
     }
     template <int BT, bool DUMP> bool launchD(wn::Params& p, int tiles, hipStream_t stream) {
@@ -245,9 +311,13 @@ protected:
     }
     template <int BT, bool EMB, bool DUMP, int RAW> void allowLdsK() {
         const size_t need = ldsNeed<BT>(m_numLayers, EMB ? embTables<BT>(DUMP) : 0, DUMP);
-        if (need <= kLdsMax)
+        if (need <= kLdsMax) {
             gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            if constexpr (lrBuilt(DUMP, RAW))      // (the whole LDS: what the tables leave free holds ring slots, placeLdsRing)
+                gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_wg<F16, R, S, A, BT, EMB, DUMP, RAW, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+        }
     }
     template <int BT, bool DUMP> void allowLdsD() {
         allowLdsK<BT, false, DUMP, 0>();
@@ -362,14 +432,21 @@ protected:
         return false;
     }
     // ... with a four-tile one (round 6): dump-free kernels only -- the folded skip-bias table is what makes room for the fourth tile's
-    // exchange images -- and for the packed / feature conditioning; other launches of such an engine take three tiles per workgroup
+    // exchange images -- and for the packed conditioning; other launches of such an engine take three tiles per workgroup
     static constexpr bool WG4 = WG3;
     bool wg4Fits() const {
         if constexpr (WG4) return ldsFits<4>(false);
         return false;
     }
     int wgTiles(int tiles) const {
-        const bool four = m_org == NVW_ORG_WG4 || (m_org == NVW_ORG_WG && tiles > WN_WG4_FROM * m_numCUs);
+        // AUTO beyond three tiles per CU: the launch runs in whole rounds of workgroups, ceil(tiles / (BT x CUs)) of them; a round of
+        // four-tile workgroups takes 1.3 times a round of three-tile ones at the socket's power limit (47 against 36 us per sample,
+        // LABNOTES round 6), so four tiles win where they save a round: (3, 4] and (6, 8] tiles per CU ...
+        bool four = m_org == NVW_ORG_WG4;
+        if (m_org == NVW_ORG_WG && tiles > WN_WG4_FROM * m_numCUs) {
+            const int r4 = (tiles + 4 * m_numCUs - 1) / (4 * m_numCUs), r3 = (tiles + 3 * m_numCUs - 1) / (3 * m_numCUs);
+            four = r4 * 47 <= r3 * 36;
+        }
         if (four && wg4Fits() && wg3Fits()) return 4;
         const bool three = four || m_org == NVW_ORG_WG3 || (m_org == NVW_ORG_WG && tiles > 2 * m_numCUs);
         if (three && wg3Fits()) return 3;
@@ -392,6 +469,7 @@ public:
           m_mulaw(NULL), m_pcmUser(NULL), m_pcmUserElems(0), m_clk(NULL), m_clkOn(false), m_stageUsed(0) {
         assert(numLayers >= 2 && batchSize > 0 && numSamples > 0 && maxDilation > 0);
         m_ringDirtyTiles = 0;
+        m_ringLdsMode = 0;
         assert(numLayers <= wn::kMaxLayers);
         {
             int dev = 0;
@@ -414,7 +492,9 @@ public:
         {
             const int tiles = (batchSize + 15) / 16;
             int group = isChain() ? 1 : wgTiles(tiles);
-            if (group == 4) group = 12;      // (launches that dump or read the conditioning in place take three tiles per workgroup)
+            // (an engine that launches four tiles per workgroup also launches three: smaller batches, launches that dump or read the
+            //  conditioning in place)
+            if (group >= 3 && wg4Fits()) group = 12;
             m_tiles = (tiles + group - 1) / group * group;
         }
 
@@ -496,8 +576,6 @@ public:
                     if (wg4Fits()) {
                         allowLdsK<4, false, false, 0>();
                         allowLdsK<4, true, false, 0>();
-                        allowLdsK<4, false, false, 3>();
-                        allowLdsK<4, true, false, 3>();
                     }
                 }
             }
@@ -575,6 +653,12 @@ public:
         if (c[3] <= c[1] || wallKHz <= 0) return 0.0;
         return (double)(c[2] - c[0]) / (double)(c[3] - c[1]) * (double)wallKHz * 1e-6;
     }
+    // The dilation ring on chip (north_star: "ring buffer staged in LDS with coalesced HBM spill"): wavenet_wg launches keep the slots
+    // of the layers with the shortest dilations in the LDS their tables leave free, loaded from / spilled to the HBM ring at the
+    // launch's ends.  mode >= 0 (default 0): as many layers as fit -- a model with a short maxDilation keeps its WHOLE ring on chip and
+    // touches the HBM ring at the ends of a launch only; C3 (maxDilation 512) keeps d <= 4 / 2 / 1 / 1 at one / two / three / four tiles
+    // per workgroup --; -1: never.  Samples are identical either way (tests/test_parity_gpu.py).
+    void setRingInLds(int mode) { m_ringLdsMode = mode < 0 ? -1 : 0; }
     // bound of every hand-off spin of the chain (default 1.5 s)
     void setChainTimeoutMs(double ms) { m_chainTimeoutTicks = (long long)(ms * 1e5); }
 
@@ -999,26 +1083,45 @@ public:
         }
         const int raw = m_featPtr ? 3 : m_condRaw ? m_condRawKind : 0;
         const int bt = launchTiles(tiles, dump, raw);
-        int nEmb = embTables<1>(dump);
+        int nEmb = planEmb<1>(dump, raw);
         size_t lds = ldsNeed<1>(m_numLayers, nEmb, dump);
         if constexpr (WG2) {
             if (bt == 2) {
-                nEmb = embTables<2>(dump);
+                nEmb = planEmb<2>(dump, raw);
                 lds = ldsNeed<2>(m_numLayers, nEmb, dump);
             }
         }
         if constexpr (WG3) {
             if (bt == 3) {
-                nEmb = embTables<3>(dump);
+                nEmb = planEmb<3>(dump, raw);
                 lds = ldsNeed<3>(m_numLayers, nEmb, dump);
             }
             if (bt == 4) {
-                nEmb = embTables<4>(dump);
+                nEmb = planEmb<4>(dump, raw);
                 lds = ldsNeed<4>(m_numLayers, nEmb, dump);
             }
         }
-        snprintf(buf, n, "wn::wavenet_wg<%s,%d,%d,%d,BT=%d,EMBLDS=%d,DUMP=%d,RAW=%d> tiles/wg=%d wgs=%d lds=%zu",
-                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, raw, bt, (tiles + bt - 1) / bt, lds);
+        // ring slots in LDS (ringPlan): the largest dilation held there, 0 = the launch keeps the whole ring in HBM
+        int ringD = 0;
+        {
+            wn::Params q;
+            fillSchedule(q);
+            size_t rb = 0;
+            if (bt == 1) rb = ringPlan<1>(q, lds, dump, raw);
+            if constexpr (WG2) {
+                if (bt == 2) rb = ringPlan<2>(q, lds, dump, raw);
+            }
+            if constexpr (WG3) {
+                if (bt == 3) rb = ringPlan<3>(q, lds, dump, raw);
+                if (bt == 4) rb = ringPlan<4>(q, lds, dump, raw);
+            }
+            lds += rb;
+            ringD = q.ldsRingD;
+        }
+        char ring[48] = "";
+        if (ringD > 0) snprintf(ring, sizeof(ring), " ring_in_lds=d<=%d", ringD);
+        snprintf(buf, n, "wn::wavenet_wg<%s,%d,%d,%d,BT=%d,EMBLDS=%d,DUMP=%d,RAW=%d%s> tiles/wg=%d wgs=%d lds=%zu%s",
+                 F16 ? "fp16" : "fp32", R, S, A, bt, nEmb, dump ? 1 : 0, raw, ringD > 0 ? ",LR=1" : "", bt, (tiles + bt - 1) / bt, lds, ring);
     }
 
     // ---- debug getters: last generated sample's activations, reference layouts --------------
@@ -1131,7 +1234,7 @@ public:
             int touched = (batch_size + 15) / 16;
             if (!(isChain() && !m_featPtr)) {
                 int bt = wgTiles(touched);
-                if (bt == 4) bt = 12;      // (three or four tiles per workgroup by launch: both roundings)
+                if (bt >= 3 && wg4Fits()) bt = 12;      // (three or four tiles per workgroup by launch: both roundings)
                 touched = (touched + bt - 1) / bt * bt;
             }
             if (touched > m_tiles) touched = m_tiles;
@@ -1175,6 +1278,7 @@ public:
         p.count = m_num_samples_per_chunk ? m_num_samples_per_chunk : num_samples;
         if (p.initSample + p.count > num_samples) p.count = num_samples - p.initSample;
         p.ringSlots = m_ringSlots;
+        p.ldsRingD = 0;                 // (the wavenet_wg launchers place ring slots in the LDS their tables leave free: placeLdsRing)
         p.tiles = m_tiles;
         p.tileBase = 0;
         p.tanhEmbed = m_tanhEmbed ? 1 : 0;
@@ -1184,19 +1288,7 @@ public:
         p.rngKey0 = (unsigned)m_rngSeed;
         p.rngKey1 = (unsigned)(m_rngSeed >> 32);
         p.clk = m_clkOn ? m_clk : NULL;
-        {
-            // dilation schedule (nv_wavenet.cuh:99,110-111) as a table in the kernel arguments: dilation and first ring slot
-            int d = 1, off = 0;
-            for (int l = 0; l < m_numLayers; l++) {
-                p.dil[l].d = d;
-                p.dil[l].off = off;
-                off += d;
-                d <<= 1;
-                if (d > m_maxDilation) d = 1;
-            }
-            p.dil[m_numLayers] = p.dil[0];
-            p.dil[m_numLayers + 1] = p.dil[1];
-        }
+        fillSchedule(p);
         m_lastStride = num_samples;
         if (p.count <= 0) return true;
 
@@ -1293,16 +1385,17 @@ protected:
         gpuErrChk(hipMemcpy(&s, m_chainStatus + i, sizeof(unsigned), hipMemcpyDeviceToHost));
         return s;
     }
-    // tiles per workgroup of THIS launch: the four-tile kernels exist dump-free and for the packed (0) / feature (3) conditioning only
+    // tiles per workgroup of THIS launch: the four-tile kernels exist dump-free and for the packed conditioning only (with the conditioning
+    // computed in the kernel a fourth tile does not fit the register file: 2-31 spilled registers by shape, and no faster -- LABNOTES round 6)
     int launchTiles(int tiles, bool dump, int raw) const {
         const int bt = wgTiles(tiles);
-        return (bt == 4 && (dump || (raw != 0 && raw != 3))) ? 3 : bt;
+        return (bt == 4 && (dump || raw != 0)) ? 3 : bt;
     }
     // wavenet_wg by batch size: one to four tiles per workgroup
     bool launchWg(wn::Params& p, int tiles, hipStream_t stream) {
         const int bt = launchTiles(tiles, p.dump != 0, p.condRawKind);
         if (bt == 4) {
-            if constexpr (WG4) return p.condRawKind == 3 ? launchE<4, false, 3>(p, tiles, stream) : launchE<4, false, 0>(p, tiles, stream);
+            if constexpr (WG4) return launchE<4, false, 0>(p, tiles, stream);
             return false;
         }
         if (bt == 3) {

@@ -234,6 +234,7 @@ unsigned nvw_chain_fallbacks(nvw_engine* e) { return e->chainFallbacks(); }
 unsigned nvw_chain_last_timeout(nvw_engine* e) { return e->chainLastTimeout(); }
 void nvw_set_chain_timeout_ms(nvw_engine* e, double ms) { e->setChainTimeoutMs(ms); }
 void nvw_set_clock_probe(nvw_engine* e, int on) { e->setClockProbe(on != 0); }
+void nvw_set_ring_in_lds(nvw_engine* e, int mode) { e->setRingInLds(mode); }
 double nvw_last_launch_clock_ghz(nvw_engine* e) { return e->lastLaunchClockGHz(); }
 int nvw_run_range(nvw_engine* e, int init_sample, int count, int num_samples, int batch_size, void* stream) {
     return e->run_range(init_sample, count, num_samples, batch_size, (hipStream_t)stream) ? 1 : 0;

@@ -24,6 +24,12 @@
 #ifndef WN_COND_VALU
 #define WN_COND_VALU 1       // packed / in-place conditioning added by v_fma_mix_f32 (1, round 6) or through 0/1 selection MFMAs (0, rounds 1-5)
 #endif
+#ifndef WN_LDS_RING_MAXD
+#define WN_LDS_RING_MAXD 512 // wavenet_wg: largest dilation whose ring slots may live in LDS during a launch (what fits is decided per launch; 0: none)
+#endif
+#ifndef WN_SOFTMAX_2PASS
+#define WN_SOFTMAX_2PASS 0   // wavenet_wg, four tiles per workgroup: sample picks in two passes of two tiles (frees LDS for the embedding table); measured: no gain
+#endif
 #ifndef WN_WG4_FROM
 #define WN_WG4_FROM 3        // AUTO: four tiles per workgroup for batches beyond this many tiles per CU (3: beyond the three-tile capacity)
 #endif

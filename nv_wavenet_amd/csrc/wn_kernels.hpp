@@ -186,7 +186,13 @@ struct Cfg {
     static constexpr int SKBUF = BT * KF_S * 1024;
     static constexpr int ZSBUF = BT * KF_A * 1024;
     static constexpr int LROW = A + 4;                     // padded logits row (floats)
-    static constexpr int LGBUF = BT * 16 * LROW * 4;
+    // the logits image holds LGT tiles at a time: four tiles per workgroup CAN pick their samples in two passes of two tiles (32.5 KiB
+    // less than one pass of four: the current tap's embedding table then fits in LDS beside the fourth tile's exchange images)
+    // (WN_SOFTMAX_2PASS, measured at 13 824 utterances, round 6: 41.6 / 42.0 us per sample against 41.3 / 41.9 in one pass with the
+    //  embedding gathers going to L2 -- the two extra barriers cost what the LDS gathers save: off)
+    static constexpr int LGT = (BT >= 4 && WN_SOFTMAX_2PASS) ? 2 : BT;
+    static_assert(BT % LGT == 0, "the softmax passes take whole groups of tiles");
+    static constexpr int LGBUF = LGT * 16 * LROW * 4;
     static constexpr int YBUF = align16(BT * 16 * 4);
     static constexpr int XPBUF = XBUF;                     // dilated tap x[t-d] as B fragments (shared by the waves)
     static constexpr int XPW = (KF_R + NW - 1) / NW;       // ring fragments owned (stored AND re-loaded) by one wave
@@ -210,6 +216,18 @@ struct Cfg {
     static size_t ldsBytes(int L, int embTables, bool dump = true) {      // embTables: 0, 1 (current tap only) or 2
         return (size_t)LDS_FIXED + (size_t)biasFloats(L, dump) * sizeof(float) + (size_t)embTables * A * R * sizeof(typename P::elem);
     }
+    // one ring slot of a workgroup in LDS: x of one (layer, sample) as B fragments, all BT tiles (the layout of the tap image XPBUF)
+    static constexpr int RING_SLOT = BT * KF_R * 1024;
+    // slots of the layers with dilation <= D (the schedule of nv_wavenet.cuh:99,110-111)
+    __host__ __device__ static constexpr int ldsRingSlots(int L, int maxDilation, int D) {
+        int n = 0, d = 1;
+        for (int l = 0; l < L; l++) {
+            if (d <= D) n += d;
+            d <<= 1;
+            if (d > maxDilation) d = 1;
+        }
+        return n;
+    }
     // per-wave stream in memory: [L][FLW] layers | [FHW] head
     __host__ __device__ static size_t headOffsetFrags(int L) { return (size_t)L * FLW; }
     __host__ __device__ static size_t waveStreamFrags(int L) { return (size_t)L * FLW + FHWP; }
@@ -219,13 +237,16 @@ struct Cfg {
 // (Params::dil, filled by the host): indexing the argument segment with a uniform layer number is a scalar load -- it does
 // not queue behind the weight prefetch like a vector load would -- and replaces ~15 scalar ALU instructions per layer of
 // schedule arithmetic (round 3).  The chain computes its few entries once per launch with dil_next.
+// lds: first slot of the layer in the LDS part of the ring (wavenet_wg, round 6: the layers with d <= Params::ldsRingD keep their d
+// slots in LDS for the length of a launch; counted over those layers only)
 struct Dil {
-    int d, off;
+    int d, off, lds;
 };
-WN_DEV Dil dil_first() { return Dil{1, 0}; }
-WN_DEV Dil dil_next(Dil s, int maxDilation, bool wrapToFirst) {
+WN_DEV Dil dil_first() { return Dil{1, 0, 0}; }
+WN_DEV Dil dil_next(Dil s, int maxDilation, bool wrapToFirst, int ldsD = 0) {
     Dil n;
     n.off = s.off + s.d;
+    n.lds = s.lds + (s.d <= ldsD ? s.d : 0);
     n.d = s.d << 1;
     if (n.d > maxDilation) n.d = 1;
     if (wrapToFirst) n = dil_first();
@@ -265,6 +286,8 @@ struct Params {
     int initSample;
     int count;               // samples generated by this launch
     int ringSlots;           // sum of dilations
+    int ldsRingD;            // wavenet_wg: layers with dilation <= this keep their ring slots in LDS during the launch (0: none), loaded from
+                             // / spilled to their places in `ring` at the launch's start / end (the state between launches lives there)
     int tiles;               // ceil(maxBatch/16): tile stride of cond / ring
     int tileBase;            // first tile of this launch (workgroup b serves tiles tileBase + b*BT ...)
     int tanhEmbed;
@@ -856,7 +879,10 @@ template <bool F16> WN_DEV void cond_add(floatx4* a, typename Prec<F16>::frag c,
 // pytorch/wavenet.py:190-202): Lh[t][l] = Wcond[l] c[t] + bcond[l] as KFC more k steps of the gate GEMM, their weights in the
 // wave's stream (Cfg<.., KFC>), their B operands -- KFC fragments per tile, 160 B per utterance instead of 2R * L values --
 // loaded once per sample.  Summation order of the gate pre-activation: (Bh + bcond), Wcond c, dilated tap, current tap.
-template <bool F16, int R, int S, int A, int BT, bool EMBLDS, bool DUMP = true, int RAW = 0>
+// LR: the launch keeps the ring slots of the short dilations in LDS (Params::ldsRingD; see ring_lds_copy).  A separate instantiation:
+// the uniform branches it puts into every layer cost 3-5 % of a sample's cycles (measured, LABNOTES round 6), which pays when most of
+// the ring traffic goes (a model whose whole ring fits) and not for two layers of twenty (C3 at three tiles per workgroup).
+template <bool F16, int R, int S, int A, int BT, bool EMBLDS, bool DUMP = true, int RAW = 0, bool LR = false>
 __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_wg(const Params p) {
     constexpr bool FEAT = RAW == 3;
     constexpr int KFC = FEAT ? feat_kfc<F16>() : 0;
@@ -1026,6 +1052,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
     // in memory, one per layer, so their resource just advances by one row per call.
     const rsrc_t rsRing = make_rsrc(ringMine);
     const unsigned ringTileB = (unsigned)ringTile;
+    // the part of the ring that is in LDS for the length of the launch (see ring_lds_copy below): layers with dilation <= ldsD
+    const int ldsD = LR ? p.ldsRingD : 0;
+    char* const ringLds = (char*)(biasLds + C::biasFloats(L, DUMP)) + (size_t)(EMBLDS ? p.embLds : 0) * A * R * sizeof(elem);
     const char* condNext = condMine + (size_t)p.initSample * L * condStride;
     // in-place conditioning: one row = [maxBatch][2R] source elements; per-lane part of the address (utterance, channel quad)
     constexpr unsigned RAWE = RAW == 2 ? 2u : 4u;                                   // bytes per source element
@@ -1043,13 +1072,15 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         const unsigned rp0 = slot * (unsigned)(KF_R * 1024);
         const rsrc_t rsCond = make_rsrc(condNext);
         condNext += condStride;
+        if (dl.d > ldsD) {                   // (a layer whose slots are in LDS has nothing to request)
 #pragma unroll
-        for (int i = 0; i < XPW; i++) {
-            const int k = w + NW * i;
-            if (k < KF_R) {                  // (one uniform branch, all tiles inside)
+            for (int i = 0; i < XPW; i++) {
+                const int k = w + NW * i;
+                if (k < KF_R) {                  // (one uniform branch, all tiles inside)
 #pragma unroll
-                for (int bt = 0; bt < BT; bt++)
-                    xd[bt][i] = buf_load<frag, WN_RING_LD_AUX>(rsRing, laneOff, rp0 + (unsigned)bt * ringTileB + (unsigned)k * 1024u);
+                    for (int bt = 0; bt < BT; bt++)
+                        xd[bt][i] = buf_load<frag, WN_RING_LD_AUX>(rsRing, laneOff, rp0 + (unsigned)bt * ringTileB + (unsigned)k * 1024u);
+                }
             }
         }
 #pragma unroll
@@ -1080,12 +1111,40 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             }
         }
     };
+    // ---- the short dilations' ring slots in LDS (round 6; north_star: "ring buffer staged in LDS with coalesced HBM spill") -------
+    // Layers with d <= ldsD keep their d slots here for the whole launch: their tap x_l[t-d] is read by every wave straight from the
+    // slot (no HBM load, no publication through the tap image), and x_l[t] replaces it from registers behind the h barrier of the
+    // layer (every wave has consumed the tap by then).  The state between launches stays in the HBM ring, same places as ever: the
+    // slots are loaded from it here and spilled back at the end of the launch, 1-KiB rows either way.  (Reference role:
+    // nv_wavenet.cuh:96-127 stages x[t-d] through shared memory out of a global ring, :334-335.)
+    auto ring_lds_copy = [&](auto TOLDS) {
+        constexpr bool toLds = decltype(TOLDS)::value;
+        if (ldsD <= 0) return;
+        Dil dl = dil_first();
+        for (int l = 0; l < L; l++) {
+            if (dl.d <= ldsD) {
+                // rows of 1 KiB: (slot, tile, fragment); wave w takes rows w, w + NW, ...
+                const int rows = dl.d * BT * KF_R;
+                for (int r = w; r < rows; r += NW) {
+                    const int sl = r / (BT * KF_R), bt = (r / KF_R) % BT, k = r % KF_R;
+                    const unsigned hb = (unsigned)(dl.off + sl) * (unsigned)(KF_R * 1024) + (unsigned)bt * ringTileB + (unsigned)k * 1024u;
+                    char* const lp = ringLds + (size_t)(dl.lds + sl) * C::RING_SLOT + ((bt * KF_R + k) * 64 + lane) * 16;
+                    if constexpr (toLds) *(frag*)lp = buf_load<frag, WN_RING_LD_AUX>(rsRing, laneOff, hb);
+                    else buf_store<frag, WN_RING_ST_AUX>(rsRing, laneOff, hb, *(const frag*)lp);
+                }
+            }
+            dl = dil_next(dl, p.maxDilation, false, ldsD);
+        }
+    };
+    ring_lds_copy(std::true_type{});
     prefetch(p.initSample, 0, p.dil[0], xpA, cdA);
     prefetch(p.initSample, 1, p.dil[1], xpB, cdB);
     // publish this wave's fragments of the NEXT layer's dilated tap to LDS.  Before the start (t < d) the tap is zero (reference
     // :287): the ring slot read then has not been written in this utterance, and the engine clears the rings when a new utterance
     // is handed over (nvWavenetInfer::resetHistory / clearRings), so the load itself brings the zeros -- no branch here.
-    auto publish_xp = [&](const frag (&xpN)[BT][XPW]) {
+    // (dN: schedule entry of the layer the tap belongs to -- its slots in LDS need no publication)
+    auto publish_xp = [&](const frag (&xpN)[BT][XPW], const Dil dN) {
+        if (dN.d <= ldsD) return;
 #pragma unroll
         for (int i = 0; i < XPW; i++) {
             const int k = w + NW * i;
@@ -1095,7 +1154,11 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             }
         }
     };
-    publish_xp(xpA);   // layer 0 (d = 1) of the first sample
+    // where the waves read the tap of (layer dN, sample tn) as B fragments: its ring slot in LDS, or the tap image
+    auto tap_image = [&](const Dil dN, int tn) -> const char* {
+        return dN.d <= ldsD ? ringLds + (size_t)(dN.lds + (tn & (dN.d - 1))) * C::RING_SLOT : xpbuf;
+    };
+    publish_xp(xpA, p.dil[0]);   // layer 0 (d = 1) of the first sample
 
     __syncthreads();   // bias table visible
 
@@ -1129,7 +1192,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         frag xp[BT][KF_R];
 #pragma unroll
         for (int bt = 0; bt < BT; bt++) {
-            lds_get_frags<F16, KF_R>(xpbuf + bt * KF_R * 1024, lane, xp[bt]);
+            lds_get_frags<F16, KF_R>(tap_image(p.dil[0], p.initSample) + bt * KF_R * 1024, lane, xp[bt]);
 #pragma unroll
             for (int i = 0; i < HTW; i++) {
                 acc[bt][2 * i] = *(const floatx4*)(biasLds + (w + NW * i) * 16 + g * 4);
@@ -1240,8 +1303,11 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             // x barrier)
             WN_TMARK(1)
             gemm_b<F16, PF, 0, BT, 2 * HTW, KF_R>(ws, rsW, SKIP ? C::P_CUR : C::P_CUR0 - PB, wl, 0, laneOff, acc, xb);
-            // x_l[t] replaces x_l[t-d] in the ring (same slot)
-            {
+            // x_l[t] replaces x_l[t-d] in the ring (same slot): in HBM right here; a layer whose slots are in LDS keeps this wave's
+            // fragments in registers and stores them behind the h barrier (other waves may still be reading the tap from that slot)
+            const bool ringInLds = d <= ldsD;
+            frag xkeep[BT][XPW];
+            if (!ringInLds) {
                 const unsigned rp = (unsigned)(dl.off + (t & (d - 1))) * (unsigned)(KF_R * 1024);
 #pragma unroll
                 for (int k = 0; k < KF_R; k++)
@@ -1250,6 +1316,13 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                         for (int bt = 0; bt < BT; bt++)
                             buf_store<frag, WN_RING_ST_AUX>(rsRing, laneOff + (unsigned)(k & 3) * 1024u,
                                                rp + (unsigned)bt * ringTileB + (unsigned)(k & ~3) * 1024u, xb[bt][k]);
+                    }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KF_R; k++)
+                    if (k % NW == w) {
+#pragma unroll
+                        for (int bt = 0; bt < BT; bt++) xkeep[bt][k / NW] = xb[bt][k];
                     }
             }
             if constexpr (!SKIP) prefetch(t, l + 2, dl2, xpC, cdC);      // (layer 0 has no skip GEMM under its gate)
@@ -1403,6 +1476,17 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             WN_TMARK(4)
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(hbuf + bt * KF_R * 1024, lane, hb[bt]);
+            if (ringInLds) {
+                char* const sl = ringLds + (size_t)(dl.lds + (t & (d - 1))) * C::RING_SLOT;
+#pragma unroll
+                for (int i = 0; i < XPW; i++) {
+                    const int k = w + NW * i;
+                    if (k < KF_R) {
+#pragma unroll
+                        for (int bt = 0; bt < BT; bt++) *(frag*)(sl + ((bt * KF_R + k) * 64 + lane) * 16) = xkeep[bt][i];
+                    }
+                }
+            }
 
             // residual accumulators start at Bres + x
             floatx4 xa[BT][HTW];
@@ -1436,7 +1520,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 }
             // dilated tap of layer l+1 (layer 0 of the next sample after the last layer), requested one and a half layers
             // ago: shared through LDS with the x exchange (the readers of the previous tap passed the h barrier)
-            publish_xp(xpN);
+            publish_xp(xpN, dN);
             __builtin_amdgcn_sched_barrier(0);
             WN_TMARK(5)
             // + conditioning of the next layer while the x stores drain (summation order of the gate pre-activation in
@@ -1466,8 +1550,9 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             WN_TMARK(7)
             // the next layer's tap and x fragments are requested; the dilated-tap GEMM runs while the latter come back
             frag xp[BT][KF_R];
+            const char* const tapImg = tap_image(dN, l + 1 < L ? t : t + 1);
 #pragma unroll
-            for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(xpbuf + bt * KF_R * 1024, lane, xp[bt]);
+            for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(tapImg + bt * KF_R * 1024, lane, xp[bt]);
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) lds_get_frags<F16, KF_R>(xbuf + bt * KF_R * 1024, lane, xb[bt]);
             __builtin_amdgcn_sched_barrier(0);
@@ -1477,8 +1562,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             // schedule entries of layers l, l+1, l+2 (the latter two may be layers 0, 1 of the next sample: table entries L, L+1)
             // the three schedule entries travel with the loop (scalar arithmetic: the scalar LOADS of the table in the kernel arguments
             // return out of order, so every LDS wait near one became an lgkmcnt(0); round 4)
-            Dil da = dil_first(), db = dil_next(da, p.maxDilation, L == 1), dc = dil_next(db, p.maxDilation, L == 2);
-            auto adv = [&](int l) { da = db; db = dc; dc = dil_next(dc, p.maxDilation, l + 3 == L); };
+            Dil da = dil_first(), db = dil_next(da, p.maxDilation, L == 1, ldsD), dc = dil_next(db, p.maxDilation, L == 2, ldsD);
+            auto adv = [&](int l) { da = db; db = dc; dc = dil_next(dc, p.maxDilation, l + 3 == L, ldsD); };
             layer(std::false_type{}, 0, da, db, dc, xpA, cdA, xpB, cdB);
             adv(0);
             int l = 1;
@@ -1550,8 +1635,8 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                     *(floatx4*)(p.zs + (size_t)ub[bt] * A + (w + NW * i) * 16 + g * 4) = zs[bt][i];
             }
         wg_barrier();
+        floatx4 za[BT][ATW];
         {
-            floatx4 za[BT][ATW];
 #pragma unroll
             for (int bt = 0; bt < BT; bt++)
 #pragma unroll
@@ -1594,17 +1679,23 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
                 if constexpr (HR >= C::FW_ZA) gemm_res<F16, BT, ATW, KF_A>(hw, C::FW_ZS - HS, za, zb);
                 else gemm_b<F16, PF, C::HSP, BT, ATW, KF_A>(ws, rsW, C::O_ZA, L * FLW, 0, laneOff, za, zb);
             }
-            if constexpr (C::ALIAS_LG) wg_barrier();   // every wave is done with the zs image
-            // logits -> LDS [utt][row] (row stride padded by 4 floats: conflict-free b128 writes)
+        }
+        if constexpr (C::ALIAS_LG) wg_barrier();   // every wave is done with the zs image
+        // logits -> LDS [utt][row] (row stride padded by 4 floats: conflict-free b128 writes), LGT tiles per softmax pass
+        constexpr int LGT = C::LGT;
+        auto put_logits = [&](auto PASS) {
+            constexpr int pass = decltype(PASS)::value;
 #pragma unroll
-            for (int bt = 0; bt < BT; bt++)
+            for (int bl = 0; bl < LGT; bl++)
 #pragma unroll
                 for (int i = 0; i < ATW; i++) {
-                    *(floatx4*)(lgbuf + (bt * 16 + j) * C::LROW + (w + NW * i) * 16 + g * 4) = za[bt][i];
+                    const int bt = pass * LGT + bl;
+                    *(floatx4*)(lgbuf + (bl * 16 + j) * C::LROW + (w + NW * i) * 16 + g * 4) = za[bt][i];
                     if (dumpNow && uvalid[bt])
                         *(floatx4*)(p.za + (size_t)ub[bt] * A + (w + NW * i) * 16 + g * 4) = za[bt][i];
                 }
-        }
+        };
+        put_logits(std::integral_constant<int, 0>{});
         WN_TMARK(8)
         if constexpr (HS == FHW) {
             skip_frags<F16, PF, C::HSP, ws_pin, C::PAD2>(ws, rsW, C::O_ZA + C::FW_ZA, L * FLW, 0, laneOff);   // (zero fragments)
@@ -1617,25 +1708,34 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         WN_TMARK(9)
 
         // ---- softmax + inverse-CDF pick: LPU lanes per utterance, RPL rows per lane (softmax_pick) ----
-#pragma unroll
-        for (int bt = 0; bt < BT; bt++) {
-            float e[C::RPL];
-            float total;
-            const float* lrow = lgbuf + (bt * 16 + su) * C::LROW + sq * C::RPL;
-            const int pick = softmax_pick<A, C::LPU, C::RPL>(lrow, sq, lane, selv[bt], e, total);
-            const int sb = (tile0 + bt) * 16 + su;
-            if (sq == 0) {
-                ybuf[bt * 16 + su] = pick;
-                if (sb < p.batch) p.yOut[(size_t)sb * p.numSamples + t] = pick;
+        static_for<BT / LGT>([&](auto PASS) {
+            constexpr int pass = decltype(PASS)::value;
+            if constexpr (pass > 0) {
+                wg_barrier();          // the previous pass's logits have been read by everyone
+                put_logits(PASS);
+                wg_barrier();
             }
-            if (dumpNow && sb < p.batch) {
-                const float inv = 1.0f / total;
 #pragma unroll
-                for (int i = 0; i < C::RPL / 4; i++)
-                    *(floatx4*)(p.p + (size_t)sb * A + sq * C::RPL + i * 4) =
-                        floatx4{e[i * 4] * inv, e[i * 4 + 1] * inv, e[i * 4 + 2] * inv, e[i * 4 + 3] * inv};
+            for (int bl = 0; bl < LGT; bl++) {
+                const int bt = pass * LGT + bl;
+                float e[C::RPL];
+                float total;
+                const float* lrow = lgbuf + (bl * 16 + su) * C::LROW + sq * C::RPL;
+                const int pick = softmax_pick<A, C::LPU, C::RPL>(lrow, sq, lane, selv[bt], e, total);
+                const int sb = (tile0 + bt) * 16 + su;
+                if (sq == 0) {
+                    ybuf[bt * 16 + su] = pick;
+                    if (sb < p.batch) p.yOut[(size_t)sb * p.numSamples + t] = pick;
+                }
+                if (dumpNow && sb < p.batch) {
+                    const float inv = 1.0f / total;
+#pragma unroll
+                    for (int i = 0; i < C::RPL / 4; i++)
+                        *(floatx4*)(p.p + (size_t)sb * A + sq * C::RPL + i * 4) =
+                            floatx4{e[i * 4] * inv, e[i * 4 + 1] * inv, e[i * 4 + 2] * inv, e[i * 4 + 3] * inv};
+                }
             }
-        }
+        });
         wg_barrier();
 #pragma unroll
         for (int bt = 0; bt < BT; bt++) {
@@ -1650,6 +1750,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
         for (int i = 0; i < 12; i++) p.p[i] = (float)tacc[i];
 #endif
 
+    ring_lds_copy(std::false_type{});      // (behind the last sample's closing barrier: every deferred slot store has landed)
     if (w == 0 && g == 0) {
 #pragma unroll
         for (int bt = 0; bt < BT; bt++)

@@ -292,6 +292,11 @@ class WavenetEngine:
     def setChainTimeoutMs(self, ms):
         lib.nvw_set_chain_timeout_ms(self._h, float(ms))
 
+    def setRingInLds(self, mode=0):
+        """The dilation ring on chip: mode >= 0 (default) = single-workgroup launches keep the ring slots of as many short-dilation layers
+        as fit in LDS; -1 = never.  Same samples either way."""
+        lib.nvw_set_ring_in_lds(self._h, int(mode))
+
     def setClockProbe(self, on=True):
         """Measurement aid: workgroup 0 of every wavenet_wg launch that follows records shader and wall clock counters."""
         lib.nvw_set_clock_probe(self._h, 1 if on else 0)

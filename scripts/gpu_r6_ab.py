@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--no-power", action="store_true")
     ap.add_argument("--crc-modes", default="wg3")
+    ap.add_argument("--ring", type=int, default=0, help="nvw_set_ring_in_lds mode of the timed launches (1: as many short-dilation layers as fit)")
     args = ap.parse_args()
     import torch
     import bench
@@ -54,10 +55,11 @@ def main():
         n = 256
         e, N, keep = bench.steady_engine(w, B, n, 11, None if args.mode == "packed" else args.mode, organisation=args.org)
         e.setClockProbe(True)
+        e.setRingInLds(args.ring)
         ms = min(bench.time_range(e, bench.STEADY_FROM, n, N, B) for _ in range(3))
         ghz = e.lastLaunchClockGHz()
         info = e.kernelInfo(B, False)
-        rec = dict(tag=args.tag, lib=os.environ.get("NVW_LIB", "shipped"), B=B, mode=args.mode, us_per_sample=round(1e3 * ms / n, 3), khz=round(n / ms, 3),
+        rec = dict(tag=args.tag, ring=args.ring, lib=os.environ.get("NVW_LIB", "shipped"), B=B, mode=args.mode, us_per_sample=round(1e3 * ms / n, 3), khz=round(n / ms, 3),
                    msamples_per_s=round(B * n / ms / 1e3, 1), clock_ghz=round(ghz, 3), cycles_per_sample=round(1e3 * ms / n * ghz * 1e3), kernel=info, crc=crc)
         if not args.no_power:
             stream = torch.cuda.current_stream().cuda_stream

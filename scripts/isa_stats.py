@@ -154,13 +154,13 @@ def kernel_sha(inst, sub):
 
 
 def kernel_sub_of(kernel_info_name):
-    """'wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0,RAW=0>' (nvw_kernel_info) -> the demangled-name substring of that kernel"""
-    m = re.match(r"wn::(\w+)<(fp16|fp32),(\d+),(\d+),(\d+),BT=(\d+),EMBLDS=(\d+),DUMP=(\d+),RAW=(\d+)>", kernel_info_name)
+    """'wn::wavenet_wg<fp16,64,256,256,BT=3,EMBLDS=1,DUMP=0,RAW=0[,LR=1]>' (nvw_kernel_info) -> the demangled-name substring of that kernel"""
+    m = re.match(r"wn::(\w+)<(fp16|fp32),(\d+),(\d+),(\d+),BT=(\d+),EMBLDS=(\d+),DUMP=(\d+),RAW=(\d+)(,LR=1)?>", kernel_info_name)
     if not m:
         return None
-    k, prec, r_, s_, a_, bt, emb, dump, raw = m.groups()
-    return "wn::%s<%s,%s,%s,%s,%s,%s,%s,%s>" % (k, "true" if prec == "fp16" else "false", r_, s_, a_, bt, "true" if int(emb) else "false",
-                                                   "true" if int(dump) else "false", raw)
+    k, prec, r_, s_, a_, bt, emb, dump, raw, lr = m.groups()
+    return "wn::%s<%s,%s,%s,%s,%s,%s,%s,%s,%s>" % (k, "true" if prec == "fp16" else "false", r_, s_, a_, bt, "true" if int(emb) else "false",
+                                                      "true" if int(dump) else "false", raw, "true" if lr else "false")
 
 
 if __name__ == "__main__":

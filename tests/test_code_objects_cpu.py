@@ -33,7 +33,7 @@ def kernel_table(obj):
 KNOWN_SPILLS = {
     "wn::wavenet_chain<true, 128, 256, 1024, false>", "wn::wavenet_chain<true, 32, 128, 256, false>", "wn::wavenet_chain<true, 32, 256, 256, false>",
     "wn::wavenet_chain<true, 64, 128, 512, false>",
-    "wn::wavenet_wg<true, 256, 256, 256, 1, false, false, 1>", "wn::wavenet_wg<true, 256, 256, 256, 1, true, false, 1>",
+    "wn::wavenet_wg<true, 256, 256, 256, 1, false, false, 1, false>", "wn::wavenet_wg<true, 256, 256, 256, 1, true, false, 1, false>",
 }
 STRICT = ("inst_64_128_256_p16.o", "inst_64_256_256_p16.o")          # BASELINE C2, C3 / C5 (the headline)
 
@@ -47,9 +47,10 @@ def test_production_kernels_of_the_fp16_engines_use_no_scratch(obj):
     gen = [r for r in rows if "wavenet_wg<" in r[0] or "wavenet_chain<" in r[0]]
     assert gen, "no generation kernel in " + obj
     for name, vgpr, agpr, sgpr, scratch, spill in gen:
-        # the last-but-one bool of wavenet_wg / the last of wavenet_chain is DUMP
+        # wavenet_wg<F16, R, S, A, BT, EMBLDS, DUMP, RAW, LR>: DUMP is the seventh argument; the last of wavenet_chain
         flags = name[name.index("<") + 1:name.rindex(">")].replace(" ", "").split(",")
-        dump = flags[-2] if "wavenet_wg<" in name else flags[-1]
+        dump = flags[6] if "wavenet_wg<" in name else flags[-1]
+        assert dump in ("true", "false"), name
         assert vgpr <= 512 and agpr <= 256 and sgpr <= 106, (name, vgpr, agpr, sgpr)
         if dump == "false" and (scratch or spill):
             assert obj not in STRICT and name in KNOWN_SPILLS, "%s: scratch %d B per lane, %d spilled registers" % (name, scratch, spill)

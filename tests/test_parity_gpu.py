@@ -316,6 +316,82 @@ def test_a_larger_batch_after_a_smaller_one_starts_from_silence(mode):
     assert np.array_equal(y2[:16], y2[16:32]) and np.array_equal(y2[:16], y2[32:])      # (the three tiles repeat the same utterances)
 
 
+# (C3's test shape has maxDilation 32: four layers of dilation 1, whose slots do not fit beside three tiles' images; C2's has 512)
+RING_CASES = [("C3", "wg", 16), ("C3", "wg2", 16), ("C2", "wg3", 16), ("C2", "wg4", 16), ("C2", "wg", 16), ("C4", "wg", 16), ("C3", "wg", 32), ("R32", "wg", 32),
+              ("oddL_ragged", "wg2", 16)]
+
+
+@pytest.mark.parametrize("name,mode,precision", RING_CASES)
+def test_ring_slots_in_lds_generate_the_same_samples(name, mode, precision):
+    """The dilation ring staged in LDS (round 6; north_star "ring buffer staged in LDS with coalesced HBM spill"; the reference stages
+    x[t-d] through shared memory out of a global ring, nv_wavenet.cuh:96-127,334-335): a wavenet_wg launch keeps the slots of as many
+    short-dilation layers as fit in LDS (the default; kernelInfo says up to which dilation; setRingInLds(-1) switches it off), loads
+    them from the HBM ring at its start and spills them back at its end.  Chunked runs (the state crosses launches through the HBM ring), a run that continues
+    an utterance generated with the ring in HBM, and the other way round, must all produce the samples of the plain kernel -- which
+    the oracle holds (test_fp16_engine_against_the_oracle_o1 / test_fp32_engine_o1_*)."""
+    case = O1_CASES[name]
+    s = case.shape
+    t = util.gen_o1(case, half=(precision == 16))
+    e0 = _engine_o1(case, t, precision, mode)
+    e0.setRingInLds(-1)
+    assert "LR" not in e0.kernelInfo(s.B, False)
+    y0 = np.full((s.B, s.N), -1, dtype=np.int32)
+    assert e0.run(s.N, s.B, y0, 1, False)
+    e0.synchronize()
+    e0.close()
+    e = _engine_o1(case, t, precision, mode)
+    info = e.kernelInfo(s.B, False)                 # (the default)
+    assert "LR=1" in info and "ring_in_lds=d<=" in info, info
+    held = int(info.split("ring_in_lds=d<=")[1].split()[0])
+    assert held >= 1
+    for chunk in (None, max(3, s.N // 5)):
+        e.setInputs(t.Lh, t.sel)
+        y = np.full((s.B, s.N), -1, dtype=np.int32)
+        if chunk:
+            assert e.run_chunks(chunk, None, s.N, s.B, y, 1)
+        else:
+            assert e.run(s.N, s.B, y, 1, False)
+        e.synchronize()
+        assert np.array_equal(y, y0), "ring in LDS (d <= %d), chunk %s: samples differ" % (held, chunk)
+    # the first half of the utterance with the ring in LDS, the second with it in HBM, and the other way round
+    half = s.N // 2
+    for first_mode, second_mode in ((0, -1), (-1, 0)):
+        e.setInputs(t.Lh, t.sel)
+        e.setRingInLds(first_mode)
+        assert e.run_partial_chunk(0, half, s.N, s.B)
+        e.setRingInLds(second_mode)
+        assert e.run_partial_chunk(half, s.N - half, s.N, s.B)
+        y = np.full((s.B, s.N), -1, dtype=np.int32)
+        e.getYOut(y, 0, s.N)
+        e.synchronize()
+        assert np.array_equal(y, y0), "ring %s then %s: samples differ" % (first_mode, second_mode)
+    e.close()
+
+
+def test_whole_ring_in_lds_when_it_fits():
+    """A model whose WHOLE ring fits the LDS a workgroup's tables leave free (short maxDilation: R64 S128 A256, 7 layers, maxDilation
+    4, fp16) keeps all of it there -- the launch touches the HBM ring at its two ends only -- and generates the samples of the
+    launch that keeps the ring in HBM (held to the oracle by test_fp16_engine_against_the_oracle_o1)."""
+    case = O1_CASES["oddL_ragged"]
+    s = case.shape
+    t = util.gen_o1(case, half=True)
+    ys = []
+    for ring_mode in (0, -1):
+        e = _engine_o1(case, t, 16, "wg")
+        e.setRingInLds(ring_mode)
+        info = e.kernelInfo(s.B, False)
+        if ring_mode == 0:
+            assert "LR=1" in info and "ring_in_lds=d<=%d" % s.maxD in info, info
+        else:
+            assert "LR" not in info, info
+        y = np.full((s.B, s.N), -1, dtype=np.int32)
+        assert e.run_chunks(case.chunk, None, s.N, s.B, y, 1)
+        e.synchronize()
+        e.close()
+        ys.append(y)
+    assert np.array_equal(ys[0], ys[1])
+
+
 def test_chain_fills_the_gpu_by_replication():
     """The multi-CU chain with as many chains as the GPU holds (C3 fp16: 5 workgroups per 16 utterances, all of
     them resident at once, chains spread over every XCD so that some hand-offs cross XCDs): 50 tiles that repeat the
@@ -1158,8 +1234,8 @@ def test_full_chip_batches_by_replication(B):
 def test_full_chip_batches_by_replication_fp16(B, impl):
     """The same property for the fp16 production path (dump-free kernels, engine's own choice of organisation at
     full-chip batch sizes; O(1) inputs): the big batch must repeat, bit for bit, what the one-tile kernel generates for
-    the 19 utterances alone (one, two and three tiles per workgroup perform the same arithmetic per utterance; beyond
-    three tiles per CU the launch has more workgroups than CUs)."""
+    the 19 utterances alone (one to four tiles per workgroup perform the same arithmetic per utterance; beyond
+    four tiles per CU the launch has more workgroups than CUs)."""
     case = cases.BY_NAME["R64S128A256_L7_B19_oddL"]
     s = case.shape
     t = util.gen_o1(case, half=True)
@@ -1173,13 +1249,15 @@ def test_full_chip_batches_by_replication_fp16(B, impl):
     # impl 1 = SINGLE_BLOCK: wavenet_wg whatever the batch; impl 0 = AUTO: beyond three tiles per CU the throughput organisation
     case = cases.Case(case.name, case.seed, case.prior, case.shape, impl, case.iters, case.chunk)
     e = _engine_o1(case, t, 16, None, B=B, Lh=np.ascontiguousarray(t.Lh[:, :, idx, :]), sel=np.ascontiguousarray(t.sel[:, idx]))
-    # the engine reports what it launches: dump-free kernels; two / three tiles per workgroup beyond one / two tiles per CU
+    # the engine reports what it launches: dump-free kernels; two / three / four tiles per workgroup beyond one / two / three tiles per CU
     import torch
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     tiles = (B + 15) // 16
     info = e.kernelInfo(B, False)
     assert "DUMP=0" in info and "fp16" in info, info
-    want = "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
+    # (beyond three tiles per CU: four tiles per workgroup where they save a round of workgroups, nvWavenetInfer::wgTiles)
+    four = tiles > 3 * ncu and -(-tiles // (4 * ncu)) * 47 <= -(-tiles // (3 * ncu)) * 36
+    want = "BT=4" if four else "BT=3" if tiles > 2 * ncu else "BT=2" if tiles > ncu else "BT=1"
     assert want in info and "wavenet_wg<" in info, (info, ncu)
     y = np.full((B, s.N), -1, dtype=np.int32)
     assert e.run(s.N, B, y, 1, False)
