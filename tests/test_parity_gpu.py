@@ -316,9 +316,12 @@ def test_a_larger_batch_after_a_smaller_one_starts_from_silence(mode):
     assert np.array_equal(y2[:16], y2[16:32]) and np.array_equal(y2[:16], y2[32:])      # (the three tiles repeat the same utterances)
 
 
-# (C3's test shape has maxDilation 32: four layers of dilation 1, whose slots do not fit beside three tiles' images; C2's has 512)
-RING_CASES = [("C3", "wg", 16), ("C3", "wg2", 16), ("C2", "wg3", 16), ("C2", "wg4", 16), ("C2", "wg", 16), ("C4", "wg", 16), ("C3", "wg", 32), ("R32", "wg", 32),
-              ("oddL_ragged", "wg2", 16)]
+# (C3's test shape has maxDilation 32: four layers of dilation 1, whose slots do not fit beside three tiles' images: C3_full below;
+#  C4, R = 128 with 30 layers, fills the LDS with its tables: no ring slot fits, the launch is the plain one)
+RING_O1_CASES = dict(O1_CASES)
+RING_O1_CASES["C3_full"] = cases.Case("C3_full_o1", 30, [], _S(64, 256, 256, 20, 16, 600, 512), 3, 1, 128)      # C3 at BASELINE's dilation range
+RING_CASES = [("C3", "wg", 16), ("C3", "wg2", 16), ("C3_full", "wg3", 16), ("C3_full", "wg4", 16), ("C2", "wg", 16), ("C2", "wg2", 16), ("C3", "wg", 32),
+              ("R32", "wg", 32), ("oddL_ragged", "wg2", 16)]
 
 
 @pytest.mark.parametrize("name,mode,precision", RING_CASES)
@@ -329,7 +332,7 @@ def test_ring_slots_in_lds_generate_the_same_samples(name, mode, precision):
     them from the HBM ring at its start and spills them back at its end.  Chunked runs (the state crosses launches through the HBM ring), a run that continues
     an utterance generated with the ring in HBM, and the other way round, must all produce the samples of the plain kernel -- which
     the oracle holds (test_fp16_engine_against_the_oracle_o1 / test_fp32_engine_o1_*)."""
-    case = O1_CASES[name]
+    case = RING_O1_CASES[name]
     s = case.shape
     t = util.gen_o1(case, half=(precision == 16))
     e0 = _engine_o1(case, t, precision, mode)
