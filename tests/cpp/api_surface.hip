@@ -88,6 +88,19 @@ static_assert(stream_layout_ok<wn::Cfg<true, 64, 256, 256, 3, wn::feat_kfc<true>
                   wn::Cfg<true, 64, 256, 256, 3, 3>::FLW == 24 && wn::feat_kfc<true>() == 3 && wn::feat_kfc<false>() == 5,
               "Cfg<.., KFC>::streamPos is not a permutation of the layer fragments");
 
+// Round 6, LDS budget arithmetic the host plans launches with (nvWavenetInfer::ldsNeed / placeLdsRing), checked at compile time at C3:
+// the dump-free bias table holds one row of skip-bias sums; three tiles then take 144 320 B with the current tap's embedding table and
+// four tiles 142 592 B without it; the ring slots of the layers with dilation <= D (nv_wavenet.cuh:99,110-111's schedule): two layers of
+// dilation 1 at maxDilation 512, 14 slots up to dilation 4, and the whole ring (15 slots) of a 7-layer model with maxDilation 4.
+using C3x3 = wn::Cfg<true, 64, 256, 256, 3>;
+using C3x4 = wn::Cfg<true, 64, 256, 256, 4>;
+static_assert(C3x3::biasFloats(20, false) == 20 * 192 + 256 + 512 && C3x3::biasFloats(20, true) == 20 * 448 + 512, "bias table");
+static_assert(C3x3::LDS_FIXED + C3x3::biasFloats(20, false) * 4 + 64 * 256 * 2 == 144320 && C3x3::LDS_FIXED + C3x3::biasFloats(20, true) * 4 + 64 * 256 * 2 == 163776,
+              "three tiles per workgroup: LDS of the dump-free / dumping kernel");
+static_assert(C3x4::LDS_FIXED + C3x4::biasFloats(20, false) * 4 == 142592 && C3x4::RING_SLOT == 8192 && C3x3::RING_SLOT == 6144, "four tiles per workgroup");
+static_assert(C3x3::ldsRingSlots(20, 512, 1) == 2 && C3x3::ldsRingSlots(20, 512, 4) == 14 && C3x3::ldsRingSlots(7, 4, 4) == 15 && C3x3::ldsRingSlots(20, 512, 0) == 0,
+              "ring slots of the short dilations");
+
 // uniform [0,1) of (tensor id, element index): a counter-based hash (splitmix64 finaliser), so that numpy restates it elementwise
 static inline float wn_test_uniform(uint32_t tensor, uint64_t i) {
     uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)tensor * 0xBF58476D1CE4E5B9ull;

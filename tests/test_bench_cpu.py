@@ -67,3 +67,30 @@ def test_socket_telemetry_reader_parses_the_gpu_metrics_table(monkeypatch):
     assert abs(s["power_w_from_energy_accumulator"] - 1375.0) < 1e-6 and s["polls"] == 2
     R.stdout = ""
     assert "power_w" not in clock_probe.read_metrics()
+
+
+def test_energy_roofline_prices_the_algorithms_counts(tmp_path, monkeypatch):
+    """roofline.energy of bench.py (round 6): SURVEY.md 8(d)'s operation counts per utterance-sample priced with the marginal energies of
+    profiles/r06_energy_ubench.json, against the socket power of the timed launch minus the power of resident idle waves.  On the
+    committed price list and a canned power reading: the parts add up to the floor, the ring is priced separately, fewer ring layers in
+    HBM cost less, four tiles per workgroup stream fewer weight bytes per utterance than three, and the fraction is floor / achieved."""
+    import bench
+    power = {"socket_w": 1380.0, "ms_per_launch": 9.5, "shader_clock_ghz": 2.0, "limit_w": 1400.0}
+    B, N = 12288, 256
+    e3 = bench.energy_roofline(power, 9.5, B, N, 3)
+    assert e3 and "error" not in e3, e3
+    assert abs(sum(e3["floor_parts_uj"].values()) - e3["floor_uj"]) < 1e-3
+    assert abs(e3["floor_with_ring_uj"] - e3["floor_uj"] - e3["ring_uj"]) < 1e-3
+    assert abs(e3["frac"] - e3["floor_uj"] / e3["achieved_uj"]) < 1e-9 and 0.3 < e3["frac"] < 1.0
+    want = (1380.0 - e3["idle_resident_waves_w"]) * 9.5e-3 / (B * N) * 1e6
+    assert abs(e3["achieved_uj"] - want) < 1e-9 and e3["achieved_total_uj"] > e3["achieved_uj"]
+    c = e3["counts_per_utterance_sample"]
+    assert c["mfma_16x16x32"] == 106.0 and c["hbm_compulsory_bytes"] == 5128 and c["weight_stream_bytes"] == bench.HEAD.weight_bytes / 48.0
+    e4 = bench.energy_roofline(power, 9.5, B, N, 4)
+    assert e4["floor_parts_uj"]["l2_weight_stream"] < e3["floor_parts_uj"]["l2_weight_stream"]
+    e18 = bench.energy_roofline(power, 9.5, B, N, 3, ring_layers_in_hbm=18)
+    assert abs(e18["ring_uj"] - 0.9 * e3["ring_uj"]) < 1e-3
+    # a byte of HBM costs far more than a MAC: what the round's levers were priced with
+    p = e3["prices_nj"]
+    assert p["hbm"] / 1024 > 50 * p["mfma16"] / 8192 and p["mfma32"] / 16384 > 0.9 * p["mfma16"] / 8192
+    assert bench.energy_roofline(None, 9.5, B, N, 3) is None
