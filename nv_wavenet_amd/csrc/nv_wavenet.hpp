@@ -414,6 +414,10 @@ protected:
         m_chainStages = m_chainLpc ? chainStagesFor(m_numLayers, m_chainLpc) : 0;
     }
     bool isChain() const { return m_chainLpc > 0; }
+    // launches whose chains serve several tiles use the instantiation that requests a unit's packed conditioning up front (wn_chain.hpp: HOIST)
+    // (built for the shapes whose stages hold at most two layers -- R = 128: C4 --, where it costs no scratch; C2 / C3 stages hold five and spill with it)
+    static constexpr bool kChainHoistBuilt = F16 && CC::SUPPORTED && CC::LP <= 2 && A <= 512;      // (the A = 1024 head spills as it is)
+    static bool chainHoists(int tpc) { return kChainHoistBuilt && tpc > WN_CHAIN_HOIST_FROM; }
     // tiles per chain for a batch of `tiles` tiles: as few as put every tile on a resident chain, at most TPC_MAX
     int chainTpc(int tiles) const {
         const int perLaunch = m_numCUs / (m_chainStages > 0 ? m_chainStages : 1);
@@ -558,6 +562,9 @@ public:
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::ldsBytes()));
             gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_chain<F16, R, S, A, false>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::ldsBytes()));
+            if constexpr (kChainHoistBuilt)      // (several tiles per chain: the instantiation that requests a unit's conditioning up front)
+                gpuErrChk(hipFuncSetAttribute((const void*)wn::wavenet_chain<F16, R, S, A, false, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CC::ldsBytes()));
             if (chainHasFallback()) {
                 gpuErrChk(hipMalloc(&m_ringShadow, ringBytes));
                 gpuErrChk(hipMalloc(&m_histShadow, 2 * (size_t)batchSize * sizeof(int)));
@@ -1076,8 +1083,9 @@ public:
         const bool dump = dumpActivations || (!F16 && !chainLaunch && (m_featPtr || m_condRaw));      // (see launch())
         if (chainLaunch) {
             const int perLaunch = m_numCUs / m_chainStages, chains = tiles < perLaunch ? tiles : perLaunch;
-            snprintf(buf, n, "wn::wavenet_chain<%s,%d,%d,%d,DUMP=%d> stages=%d layers/stage=%d chains=%d tiles/chain=%d wgs=%d lds=%zu",
-                     F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, m_chainStages, m_chainLpc, chains, chainTpc((m_maxBatch + 15) / 16),
+            const int tpcNow = chainTpc((m_maxBatch + 15) / 16);
+            snprintf(buf, n, "wn::wavenet_chain<%s,%d,%d,%d,DUMP=%d%s> stages=%d layers/stage=%d chains=%d tiles/chain=%d wgs=%d lds=%zu",
+                     F16 ? "fp16" : "fp32", R, S, A, dump ? 1 : 0, (!dump && chainHoists(tpcNow)) ? ",HOIST=1" : "", m_chainStages, m_chainLpc, chains, tpcNow,
                      m_chainStages * chains, CC::ldsBytes());
             return;
         }
@@ -1455,7 +1463,14 @@ protected:
             if (dump) {
                 hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, true>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
             } else {
-                hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, false>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
+                bool hoisted = false;
+                if constexpr (kChainHoistBuilt) {
+                    if (chainHoists(tpc)) {
+                        hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, false, true>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
+                        hoisted = true;
+                    }
+                }
+                if (!hoisted) hipLaunchKernelGGL((wn::wavenet_chain<F16, R, S, A, false>), dim3(grid), dim3(C::THREADS), CC::ldsBytes(), stream, p, cp);
             }
             if (hipGetLastError() != hipSuccess) return false;
             if (fallback) {

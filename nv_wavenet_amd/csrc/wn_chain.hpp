@@ -349,7 +349,13 @@ WN_DEV void gemm_w(const floatx4 (&wag)[CC::NAG ? CC::NAG : 1], const typename P
 // ------------------------------------------------------------------------------------------------
 // layer stage: layers l0 .. l0+nl-1 of tile `tile`
 // ------------------------------------------------------------------------------------------------
-template <bool F16, int R, int S, int A, bool DUMP>
+// HOIST (round 6; launches with several tiles per chain): the packed conditioning of ALL own layers is requested in front of the
+// first layer's use instead of layer by layer -- the HBM part of a unit's "idle work", which a saturated stage pays once per tile
+// and sample (measured in round 5 as an experiment build at C4: five tiles per chain 24.0 -> 25.0 kHz, one and four tiles unchanged,
+// but the registers it holds across the idle work cost the one-tile launches 4 % -- C2 B = 4 84.1 -> 80.5 kHz --: hence a separate
+// instantiation, launched only when a chain serves more than four tiles: round 6, A/B in one GPU call, steady-state kHz per utterance at C4
+// with / without: 4 tiles 27.5 / 27.7, 5 tiles 24.4 - 24.7 / 23.5 - 23.8 -- 1 280 utterances per GPU in real time --, 6 tiles 20.8 / 20.0).
+template <bool F16, int R, int S, int A, bool DUMP, bool HOIST>
 WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int chainIdx, int stage) {
     using CC = CCfg<F16, R, S, A>;
     using C = typename CC::C;
@@ -463,6 +469,18 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
 
         // ---- while the sample is on its way: conditioning + dilated-tap GEMMs of all own layers ------
         floatx4 acc[LP][2 * HTW];
+        frag cdAll[HOIST ? LP : 1][C::COND_FR];
+        if constexpr (HOIST) {
+            if (p.condRawKind == 0) {
+#pragma unroll
+                for (int li = 0; li < LP; li++)
+                    if (li < nl) {
+                        const char* cp0 = condMine + ((size_t)t * L + (l0 + li)) * condStride;
+#pragma unroll
+                        for (int k = 0; k < C::COND_FR; k++) cdAll[li][k] = *(const frag*)(cp0 + k * 1024 + laneOff);
+                    }
+            }
+        }
 #pragma unroll
         for (int li = 0; li < LP; li++) {
             if (li < nl) {
@@ -496,7 +514,10 @@ WN_DEV void chain_layers(const Params& p, const ChainParams& cp, char* lds, int 
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < C::COND_FR; k++) cd[0][k] = *(const frag*)(cp0 + k * 1024 + laneOff);
+                    for (int k = 0; k < C::COND_FR; k++) {
+                        if constexpr (HOIST) cd[0][k] = cdAll[li][k];
+                        else cd[0][k] = *(const frag*)(cp0 + k * 1024 + laneOff);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < HTW; i++) {
@@ -936,7 +957,7 @@ static __global__ void chain_settle_kernel(unsigned* status) {
 
 // One workgroup per (tile, stage).  Workgroup b is observed to run on XCD b % 8: the stages of a chain
 // take workgroups of one residue class so that a chain's granules stay in one L2 (speed only).
-template <bool F16, int R, int S, int A, bool DUMP>
+template <bool F16, int R, int S, int A, bool DUMP, bool HOIST = false>
 __global__ __launch_bounds__((Cfg<F16, R, S, A, 1>::THREADS), 1) void wavenet_chain(const Params p, const ChainParams cp) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if constexpr (!CCfg<F16, R, S, A>::SUPPORTED) return;   // not even one layer fits a CU: never launched
@@ -946,7 +967,7 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, 1>::THREADS), 1) void wavenet_ch
     const int chainIdx = (q / cp.stages) * 8 + xcd;
     if (chainIdx >= cp.chains) return;
     if (stage == cp.stages - 1) chain_head<F16, R, S, A, DUMP>(p, cp, lds, chainIdx);
-    else chain_layers<F16, R, S, A, DUMP>(p, cp, lds, chainIdx, stage);
+    else chain_layers<F16, R, S, A, DUMP, HOIST>(p, cp, lds, chainIdx, stage);
 }
 
 }  // namespace wn

@@ -30,6 +30,10 @@
 #ifndef WN_SOFTMAX_2PASS
 #define WN_SOFTMAX_2PASS 0   // wavenet_wg, four tiles per workgroup: sample picks in two passes of two tiles (frees LDS for the embedding table); measured: no gain
 #endif
+#ifndef WN_CHAIN_HOIST_FROM
+#define WN_CHAIN_HOIST_FROM 4  // wavenet_chain: launches with more tiles per chain than this use the HOIST instantiation (99: never).  Measured at C4,
+                               // steady-state kHz per utterance with / without: 4 tiles 27.5 / 27.7, 5 tiles 24.4 - 24.7 / 23.5 - 23.8, 6 tiles 20.8 - 20.9 / 19.9 - 20.0
+#endif
 #ifndef WN_WG4_FROM
 #define WN_WG4_FROM 3        // AUTO: four tiles per workgroup for batches beyond this many tiles per CU (3: beyond the three-tile capacity)
 #endif

@@ -447,6 +447,8 @@ def test_chain_with_several_tiles_per_chain(name, tpc, precision):
     e = _engine_o1(case, t, precision, "chain", B=B, Lh=np.ascontiguousarray(t.Lh[:, :, idx, :]), sel=np.ascontiguousarray(t.sel[:, idx]))
     info = e.kernelInfo(B, False)
     assert "wavenet_chain<" in info and "chains=%d tiles/chain=%d " % (chains, tpc) in info, info
+    # (round 6: beyond four tiles per chain the two-layer stages of R = 128 run the instantiation that requests a unit's conditioning up front)
+    assert ("HOIST=1" in info) == (name == "C4" and tpc > 4), info
     y = np.full((B, s.N), -1, dtype=np.int32)
     assert e.run_chunks(case.chunk, None, s.N, B, y, 1)
     e.synchronize()
