@@ -11,10 +11,11 @@ from nv_wavenet_amd import WavenetEngine
 def main():
     R, S, A, L, B = [int(x) for x in sys.argv[1:6]]
     org = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+    prec = int(sys.argv[7]) if len(sys.argv) > 7 else 16
     N = 64
     rng = np.random.default_rng(1)
     u = lambda sc, *shape: ((rng.random(shape, dtype=np.float32) - 0.5) * sc).astype(np.float32)
-    e = WavenetEngine(R, S, A, L, 512, B, N, impl=0, precision=16, organisation=org)
+    e = WavenetEngine(R, S, A, L, 512, B, N, impl=0, precision=prec, organisation=org)
     info = e.kernelInfo(B, True)
     print(info)
     K = int(info.split("stages=")[1].split()[0])
