@@ -546,6 +546,39 @@ def test_fp16_three_tiles_per_workgroup_identical(B):
     e.close()
 
 
+@pytest.mark.parametrize("B", [16, 70, 200])
+def test_fp16_four_tiles_per_workgroup_identical(B):
+    """Round 6: wavenet_wg with FOUR tiles of 16 utterances per workgroup (dump-free launches with packed conditioning) against the
+    one-tile kernel, which the oracle checks: one tile in a group of four, partly filled groups (a ragged last tile), several groups;
+    one launch and chunked -- the last chunk of run_chunks can dump and therefore runs three tiles per workgroup on the same rings --;
+    conditioning read in place takes the three-tile kernels as well (the engine reports which)."""
+    import torch
+    case = O1_CASES["C3"]
+    s = case.shape
+    t, y16 = _fp16_checked_run("C3", "wg")
+    idx = np.arange(B) % s.B
+    Lh = np.ascontiguousarray(t.Lh[:, :, idx, :])
+    sel = np.ascontiguousarray(t.sel[:, idx])
+    e = _engine_o1(case, t, 16, "wg4", B=B, Lh=Lh, sel=sel)
+    assert "BT=4" in e.kernelInfo(B, False) and "BT=3" in e.kernelInfo(B, True), (e.kernelInfo(B, False), e.kernelInfo(B, True))
+    Lh16 = torch.from_numpy(Lh).cuda().half()
+    for chunk, direct in ((None, None), (100, None), (37, None), (None, Lh16)):
+        e.setInputs(Lh, sel)
+        if direct is not None:
+            e.setConditioningDirect(direct)
+            info = e.kernelInfo(B, False)
+            assert "RAW=2" in info and "BT=3" in info, info
+        y = np.full((B, s.N), -1, dtype=np.int32)
+        if chunk:
+            assert e.run_chunks(chunk, None, s.N, B, y, 1)
+        else:
+            assert e.run(s.N, B, y, 1, False)
+        e.synchronize()
+        bad = np.argwhere((y != y16[idx]).any(axis=1))
+        assert bad.size == 0, "utterance %d differs (chunk %s, in place %s)" % (int(bad[0, 0]), chunk, None if direct is None else direct.dtype)
+    e.close()
+
+
 @pytest.mark.parametrize("precision", [32, 16])
 @pytest.mark.parametrize("mode", ["wg", "wg2", "wg3", "chain"])
 def test_conditioning_consumed_in_place(mode, precision):
