@@ -7,7 +7,7 @@ including the per-chunk copies of the samples to the host).
   -l layers  -r R  -s S  -a A  -b batch  -c batch_size_per_block  -n samples  -d max_dilation
   -m mode (0 AUTO 1 SINGLE 2 DUAL 3 PERSISTENT 4 MANYBLOCK)  -p precision (16|32)
   -t samples_per_chunk  -f device
-Extension: -o organisation (0 = from -m and the batch size, 1..6 see include/nv_wavenet_c.h: nvw_create_ex);
+Extension: -o organisation (0 = from -m and the batch size, 1..6 and 10 see include/nv_wavenet_c.h: nvw_create_ex);
 the line "kernel: ..." reports the device code that ran.
 """
 import argparse
