@@ -1105,7 +1105,7 @@ def main():
             assert kname == HEADLINE_KERNELS[bt].replace("RAW=0", "RAW=3" if args.conditioning == "features" else "RAW=0"), kinfo     # the launches the parity tests pin
         # workgroups (weight-stream passes) per sample
         passes = (tiles + bt - 1) // bt
-        traffic, lds_counter, traffic_file = None, None, None
+        traffic, lds_counter, traffic_file, counters = None, None, None, None
         # HBM and LDS bytes per launch from the PMC passes of the latest profiled round (profiles/traffic_rNN.json, written
         # by scripts/make_profiles_r*.py from rocprofv3 counters); only valid for the launch shape it was measured on
         # ... AND for the device code it was measured on: the file carries the kernel's name and the sha256 of its instruction stream
@@ -1130,6 +1130,7 @@ def main():
                         break
                     traffic = tj.get("hbm_bytes_per_launch")
                     lds_counter = tj.get("lds_bytes_per_launch")
+                    counters = tj
                     traffic_file = os.path.relpath(tf, ROOT)
                     traffic_note = "rocprofv3 counters of this launch shape and this device code (%s)" % traffic_file
                     break
@@ -1164,6 +1165,24 @@ def main():
             en = energy_roofline(power, kern_ms, B, N, bt, args.conditioning == "features", ring_layers_in_hbm=ring_layers)
             if en:
                 roofline["energy"] = en
+                # ... and the same price list on what the launch ACTUALLY issued and moved (rocprofv3 counters of this kernel and launch shape,
+                # profiles/traffic_rNN.json): does the sum of the priced operations explain the energy the socket reports?
+                if counters and "prices_nj" in en and not chain_mode:
+                    try:
+                        pn = en["prices_nj"]
+                        mf = HEAD.macs / 8192.0
+                        act = {"mfma": mf * pn["mfma16"], "valu_and_transcendental": counters["valu_per_mfma"] * mf * pn["valu"],
+                               "lds": counters["lds_bytes_per_workgroup_sample"] / (16.0 * bt) / 1024.0 * pn["lds"],
+                               "l2_weight_stream": HEAD.weight_bytes / (16.0 * bt) / 1024.0 * pn["l2"],
+                               "hbm_read": counters["hbm_read_bytes_per_utterance_sample"] / 1024.0 * pn["hbm"],
+                               "hbm_write": counters["hbm_write_bytes_per_utterance_sample"] / 1024.0 * pn["hbmw"]}
+                        en["priced_counters_uj"] = sum(act.values()) * 1e-3
+                        en["priced_counters_parts_uj"] = {k: round(v * 1e-3, 4) for k, v in act.items()}
+                        en["priced_counters_over_achieved"] = en["priced_counters_uj"] / en["achieved_uj"]
+                        en["priced_counters_note"] = ("the price list applied to the instructions issued and bytes moved per utterance-sample (SQ_INSTS_VALU / SQ_INSTS_MFMA, "
+                                                      "SQ_INSTS_LDS_*_BANDWIDTH, FETCH_SIZE x2, WRITE_SIZE of %s): how much of the measured dynamic energy the priced operations explain" % traffic_file)
+                    except Exception:
+                        pass
             # what binds: with every CU busy the socket sits at its power limit and gives the clock away -- the launch is
             # bound by joules per utterance-sample, not by the matrix pipe nor by HBM
             if power.get("limit_w") and power.get("socket_w", 0) >= 0.95 * power["limit_w"]:
