@@ -1,6 +1,10 @@
 set -x
 cd $GRAFT_REPO_ROOT
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke17.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke17.log
-python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/t17.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/b17.json 2> gpurun_out/b17.err
-tail -3 gpurun_out/smoke17.log; tail -3 gpurun_out/t17.log; tail -2 gpurun_out/b17.err
+for v in shipped p18 p3 p19 p16 shipped p18 p3 p19 p16; do
+  if [ $v = shipped ]; then unset NVW_LIB; else export NVW_LIB=$PWD/scripts/ubench/bld_$v/libwavenet_infer.so; fi
+  python scripts/gpu_r6_ab.py $v --batches 12288 --crc-modes wg3 >> gpurun_out/ab18.log 2>&1
+done
+grep -h "^{" gpurun_out/ab18.log | python -c "
+import sys,json
+for l in sys.stdin:
+    r=json.loads(l); print(r['tag'],r['B'],r['us_per_sample'],r['clock_ghz'],r['cycles_per_sample'],r.get('socket_w'),r.get('uj_per_utterance_sample'),r['crc'])"
