@@ -11,7 +11,7 @@
 // What is different underneath.  `Implementation` selects between device-code ORGANISATIONS of the
 // same MFMA engine (all parity-tested against each other and the oracle):
 //   SINGLE_BLOCK            one workgroup runs the whole network for its utterance tile(s), weights
-//                           streamed from L2 every sample: wn::wavenet_wg with 1, 2 or 3 tiles of 16
+//                           streamed from L2 every sample: wn::wavenet_wg with 1 to 4 tiles of 16
 //                           utterances per workgroup by batch size
 //   DUAL_BLOCK, PERSISTENT  wn::wavenet_chain: the layer stack split over a chain of CUs, each holding
 //                           its layers' weights resident in registers + LDS, plus a head CU; hand-offs
@@ -51,7 +51,7 @@ inline void wnGpuAssert(hipError_t code, const char* file, int line, bool abort 
 // kernel organisations (beyond the reference: its Implementation enum maps onto these, see above)
 enum nvwOrganisation {
     NVW_ORG_AUTO = 0,     // from Implementation and the batch size
-    NVW_ORG_WG = 1,       // wn::wavenet_wg, 1, 2 or 3 tiles per workgroup by batch size
+    NVW_ORG_WG = 1,       // wn::wavenet_wg, 1 to 4 tiles per workgroup by batch size
     NVW_ORG_WG1 = 2,      // wn::wavenet_wg, one tile per workgroup
     NVW_ORG_WG2 = 3,      // wn::wavenet_wg, two tiles per workgroup
     NVW_ORG_WG3 = 4,      // wn::wavenet_wg, three tiles per workgroup (fp16, R <= 64; else two)
@@ -353,8 +353,8 @@ protected:
     bool chainFits(int lpc, int tiles) const {
         return lpc > 0 && chainStagesFor(m_numLayers, lpc) * ((tiles + CC::TPC_MAX - 1) / CC::TPC_MAX) <= m_numCUs;
     }
-    // The single-workgroup organisation: one, two or -- fp16, R <= 64 -- three tiles per workgroup (split over the 4 SIMDs
-    // of a CU) by batch size, see wgTiles(); beyond three tiles per CU the launch simply has more workgroups than CUs.
+    // The single-workgroup organisation: one, two or -- fp16, R <= 64 -- three or four tiles per workgroup (split over the 4 SIMDs
+    // of a CU) by batch size, see wgTiles(); beyond four tiles per CU the launch has more workgroups than CUs.
     int singleOrg(int) const { return NVW_ORG_WG; }
     // Per-sample time models (microseconds) of the organisations that can run `tiles` tiles, from the shape: weight bytes per
     // sample W, layers L, CUs.  Every constant is a measurement on MI355X, kept with its source:
@@ -491,7 +491,7 @@ public:
             fprintf(stderr, "nvWavenetInfer: R=%d S=%d A=%d with %d layers needs %zu bytes of LDS (> 160 KiB): unsupported\n", R,
                     S, A, numLayers, ldsNeed<1>(numLayers, 0));
 
-        // conditioning / ring are allocated for whole workgroups (two or three tiles per workgroup may be chosen), else
+        // conditioning / ring are allocated for whole workgroups (two to four tiles per workgroup may be chosen), else
         // exactly the tiles of the batch
         {
             const int tiles = (batchSize + 15) / 16;

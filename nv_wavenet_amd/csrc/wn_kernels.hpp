@@ -7,7 +7,7 @@
 //
 //   * The batch is the MFMA N dimension.  Every mat-vec of the reference (one thread per output
 //     row, K weights in that thread's registers, nv_wavenet.cuh:131-157, matrix_math.cuh:80-157)
-//     becomes a [M x K] x [K x 16] MFMA GEMM over a tile of 16 utterances (BT tiles per
+//     becomes a [M x K] x [K x 16] MFMA GEMM over a tile of 16 utterances (BT = 1 .. 4 tiles per
 //     workgroup share one pass over the weights).
 //   * One workgroup = NW (4) wavefronts, one per SIMD, all working on the SAME utterance tile:
 //     the M (output-row) dimension of every GEMM is split across the waves, so each wave streams
@@ -28,7 +28,10 @@
 //   * Biases live in LDS for the whole launch and initialise the MFMA accumulators.
 //   * The dilated history x_l[t-d_l] is a ring of exactly d_l slots per layer in global memory
 //     (B-fragment order, 1-KiB coalesced rows): sum(d_l)*R*16 elements per tile instead of the
-//     reference's (maxDilation+1)*(L+1) planes (nv_wavenet.cuh:334-335).
+//     reference's (maxDilation+1)*(L+1) planes (nv_wavenet.cuh:334-335).  Round 6: during a launch the slots of the layers with the
+//     shortest dilations -- as many as the LDS holds behind the tables, the whole ring for models with a short maxDilation -- live
+//     in LDS (the LR instantiations of wavenet_wg: ring_lds_copy / tap_image; the reference stages x[t-d] through shared memory,
+//     nv_wavenet.cuh:96-127), loaded from and spilled to their places in that global ring at the launch's ends.
 //   * VMEM returns in order per wave.  Everything the weight stream could delay is kept off that
 //     path (dilation schedule in scalar arithmetic, biases / embeddings in LDS), and the slow HBM
 //     loads (conditioning, dilated tap) that could delay the weight stream are requested two layers
