@@ -1006,7 +1006,7 @@ def main():
         for name, dt in (("fragment_order", "fragments"), ("fp16_tensor", torch.float16), ("fp32_tensor", torch.float32)):
             ip_sweep = {}
             k_ip, info_ip = 0.0, ""
-            for cand in [B] + [c for c in (32 * ncu, 16 * ncu) if c < B]:
+            for cand in [B] + [c for c in (44 * ncu, 40 * ncu, 36 * ncu, 32 * ncu, 16 * ncu) if c < B]:
                 if extras_left() < 20:
                     skipped.append("end_to_end.in_place.%s.%d" % (name, cand))
                     break

@@ -250,11 +250,11 @@ protected:
         p.dil[m_numLayers + 1] = p.dil[1];
         return (size_t)slot * CB::RING_SLOT;
     }
-    // ... and whether a launch uses them (the LR instantiations of wavenet_wg: dump-free, packed or -- fp16 -- feature conditioning).
+    // ... and whether a launch uses them (the LR instantiations of wavenet_wg: the dump-free kernels).
     // m_ringLdsMode >= 0 (default): as many of the short dilations as fit; -1: never.  Measured at C3 (LABNOTES round 6, us per sample
     // with / without): one tile per workgroup, d <= 4 on chip, 21.1 / 21.7; two tiles, d <= 2 in the place of the older tap's
     // embedding table, 28.4 / 29.2; three tiles, d <= 1, 37.3 / 37.4; four tiles, d <= 1, 43.6 / 44.2.
-    static constexpr bool lrBuilt(bool dump, int raw) { return !dump && (raw == 0 || (raw == 3 && F16)); }
+    static constexpr bool lrBuilt(bool dump, int raw) { return !dump && (raw == 0 || F16); }      // (fp32 engines: dump-free code exists for the packed conditioning only)
     template <int BT> size_t ringPlan(wn::Params& p, size_t need, bool dump, int raw) const {
         p.ldsRingD = 0;
         if (!lrBuilt(dump, raw) || m_ringLdsMode < 0) return 0;

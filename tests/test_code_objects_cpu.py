@@ -34,6 +34,7 @@ KNOWN_SPILLS = {
     "wn::wavenet_chain<true, 128, 256, 1024, false, false>", "wn::wavenet_chain<true, 32, 128, 256, false, false>",
     "wn::wavenet_chain<true, 32, 256, 256, false, false>", "wn::wavenet_chain<true, 64, 128, 512, false, false>",
     "wn::wavenet_wg<true, 256, 256, 256, 1, false, false, 1, false>", "wn::wavenet_wg<true, 256, 256, 256, 1, true, false, 1, false>",
+    "wn::wavenet_wg<true, 256, 256, 256, 1, false, false, 1, true>", "wn::wavenet_wg<true, 256, 256, 256, 1, true, false, 1, true>",
 }
 STRICT = ("inst_64_128_256_p16.o", "inst_64_256_256_p16.o")          # BASELINE C2, C3 / C5 (the headline)
 
