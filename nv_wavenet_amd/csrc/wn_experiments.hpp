@@ -37,6 +37,9 @@
 #ifndef WN_WG4_FROM
 #define WN_WG4_FROM 3        // AUTO: four tiles per workgroup for batches beyond this many tiles per CU (3: beyond the three-tile capacity)
 #endif
+#ifndef WN_HEADREGS4
+#define WN_HEADREGS4 0       // ... four tiles per workgroup: the whole head is streamed (428 - 440 registers without it)
+#endif
 #ifndef WN_TAKE_G
 #define WN_TAKE_G 1          // wavenet_wg: weight fragments waited for together (take_group); > 1 measured slower
 #endif

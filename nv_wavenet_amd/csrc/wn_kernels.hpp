@@ -163,7 +163,8 @@ struct Cfg {
     static constexpr int HR = !F16 ? 0
                               : BT == 1 ? (FW_ZA * 4 <= WN_HEADREGS ? FW_ZA : 0)
                               : BT == 2 ? (FW_ZA * 4 <= WN_HEADREGS2 ? FW_ZA : 0)
-                                        : (FW_ZA * 4 <= WN_HEADREGS3 ? FW_ZA : 0);
+                              : BT == 3 ? (FW_ZA * 4 <= WN_HEADREGS3 ? FW_ZA : 0)
+                                        : (FW_ZA * 4 <= WN_HEADREGS4 ? FW_ZA : 0);
     static constexpr int HS = FHW - HR;
     static constexpr bool HEADRES = HS == 0;              // the stream cycles over the layers only
     // The head's part of a wave's stream is laid out  zs | PAD1 | za | PAD2  with zero fragments that bring each matrix
