@@ -163,4 +163,34 @@ if have("prof6b_kt"):
                   20 * 2 * 64 * 2 + RING_L * 64 * 2 + 4, RING_L * 64 * 2 + 4, "conditioning 5120 + dilated taps of the 18 layers with d > 1: 2304 + selector",
                   f"{P}/r06_kernel_trace_stats_wg_b13824.txt", f"{P}/r06_pmc_wg_b13824.txt", f"{P}/traffic_r06_b13824.json")
     print("13824 (BT=4): HBM read %.0f write %.0f B per utterance-sample" % r)
+# ---- C: the chain at C4, five tiles per chain (HOIST) ---------------------------------------------------------------------------------------
+if have("prof6c_kt"):
+    doc = load("prof6c_kt")
+    line = json.load(open(f"{G}/prof6c_line.json"))
+    ks = [(k, v) for k, v in doc["kernels"].items() if "wavenet_chain" in k]
+    FLOP4 = 7143424
+    B4 = line["batch"]
+    with open(f"{P}/r06_chain_c4_five_tiles_per_chain.txt", "w") as f:
+        f.write("# round 6: python scripts/gpu_r6_chain.py prof 5  under  rocprofv3 --kernel-trace --stats (+ FETCH_SIZE / WRITE_SIZE passes in their own runs)\n")
+        f.write("# %s\n" % line["kernel"])
+        f.write("# 16 chains x 16 CUs (15 stages of 2 layers + head), FIVE tiles per chain = %d utterances per GPU; the stages request a unit's packed\n"
+                "# conditioning of both layers up front (HOIST).  The script's own line: steady-state kHz per utterance %s (samples 640..1663)\n" % (B4, line["steady_khz"]))
+        for name, k in ks:
+            d = sorted(k["durations_ns"])
+            f.write("# %s: %d launches; the longest (1024 steady-state samples x %d utterances): %.2f ms = %.2f us per sample = %.2f kHz per utterance; "
+                    "%.1f TFLOP/s = %.4f of 2500 dense fp16\n" % (demangle(name)[:70], k["calls"], B4, d[-1] / 1e6, d[-1] / 1e3 / 1024, 1024 / (d[-1] / 1e6),
+                                                                 B4 * 1024 * FLOP4 / (d[-1] * 1e-9) / 1e12, B4 * 1024 * FLOP4 / (d[-1] * 1e-9) / PEAK))
+        f.write(stats_table(doc, 8))
+        c = {}
+        for dd in ("fetch", "write"):
+            if have(f"prof6c_{dd}"):
+                c.update(pmc_of(load(f"prof6c_{dd}"), "wavenet_chain"))
+        if "FETCH_SIZE" in c:
+            tot_us = B4 * 2 * (640 + 1024)          # two probes, each a 640-sample run-in and 1024 timed samples
+            f.write("# HBM over all chain launches of the run (%d utterance-samples): read %.0f B, written %.0f B per utterance-sample\n" %
+                    (tot_us, 2 * c["FETCH_SIZE"] * 1024 / tot_us, c["WRITE_SIZE"] * 1024 / tot_us))
+            f.write("#   (algorithmic: conditioning 15 360 + dilated taps 7 680 read, ring 7 680 written; the rest is the hand-off -- 8-byte {value, tag} granules,\n"
+                    "#    1 KiB of x per utterance and stage + 2 KiB of skip sums over 15 + 16 hops -- as in round 5)\n")
+        for kk in sorted(c):
+            f.write("%-32s %20.0f\n" % (kk, c[kk]))
 print("done")
