@@ -257,6 +257,9 @@ protected:
     static constexpr bool lrBuilt(bool dump, int raw) { return !dump && (raw == 0 || F16); }      // (fp32 engines: dump-free code exists for the packed conditioning only)
     template <int BT> size_t ringPlan(wn::Params& p, size_t need, bool dump, int raw) const {
         p.ldsRingD = 0;
+#ifdef WN_EXP_TWO_WG
+        if (BT == 1) return 0;
+#endif
         if (!lrBuilt(dump, raw) || m_ringLdsMode < 0) return 0;
         wn::Params q = p;
         const size_t bytes = placeLdsRing<BT>(q, need);
@@ -284,6 +287,9 @@ protected:
     // OLDER tap's table for ring slots (its gather is one sample early, off the dependent chain; C3 at two tiles: 28.4 against 29.2 us)
     template <int BT> int planEmb(bool dump, int raw) const {
         int nEmb = embTables<BT>(dump);
+#ifdef WN_EXP_TWO_WG
+        if (BT == 1) return 0;      // (experiment: two workgroups per CU: 80 KiB of LDS each)
+#endif
         if (nEmb == 2 && m_ringLdsMode >= 0 && lrBuilt(dump, raw)) {
             wn::Params q;
             fillSchedule(q);
@@ -443,6 +449,9 @@ protected:
         return false;
     }
     int wgTiles(int tiles) const {
+#ifdef WN_EXP_TWO_WG
+        if (m_org == NVW_ORG_WG && tiles <= 2 * m_numCUs) return 1;      // (experiment: up to two one-tile workgroups per CU)
+#endif
         // AUTO beyond three tiles per CU: the launch runs in whole rounds of workgroups, ceil(tiles / (BT x CUs)) of them; a round of
         // four-tile workgroups takes 1.3 times a round of three-tile ones at the socket's power limit (47 against 36 us per sample,
         // LABNOTES round 6), so four tiles win where they save a round: (3, 4] and (6, 8] tiles per CU ...

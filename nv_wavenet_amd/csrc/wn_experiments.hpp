@@ -87,6 +87,9 @@
 // taken out of wn_kernels.hpp in round 5: their measurements are in LABNOTES.md (rounds 2-4), their code in commit c19e716.  What they
 // were built to decide -- whether the full-chip launch is bound by its memory traffic -- was settled by removing the conditioning
 // stream for real (round 5).
+//   WN_EXP_TWO_WG    round 6: the one-tile wavenet_wg with a register budget for TWO workgroups per CU (two waves per SIMD, each with its own tile
+//                    and weight stream; no embedding table / ring slots in LDS), AUTO launching one-tile workgroups up to two tiles per CU: the A/B of
+//                    the round-5 review's item 4 (8 192 utterances: 40.2 us per sample against 27.7 for the two-tile workgroup; LABNOTES round 6)
 // ---- probes (results stay right) ------------------------------------------------------------------------------------------
 //   WN_TIMING        wavenet_wg: per-phase shader-clock sums of wave 0 into Params::p (scripts/quick_phase.py)
 //   WN_CHAIN_TIMING  wavenet_chain: wall-clock stamps per stage (scripts/chain_phase.py)

@@ -887,7 +887,13 @@ template <bool F16> WN_DEV void cond_add(floatx4* a, typename Prec<F16>::frag c,
 // the uniform branches it puts into every layer cost 3-5 % of a sample's cycles (measured, LABNOTES round 6), which pays when most of
 // the ring traffic goes (a model whose whole ring fits) and not for two layers of twenty (C3 at three tiles per workgroup).
 template <bool F16, int R, int S, int A, int BT, bool EMBLDS, bool DUMP = true, int RAW = 0, bool LR = false>
+// (WN_EXP_TWO_WG, experiment build of round 6: the one-tile kernel with a register budget that lets TWO workgroups share a CU -- two waves per
+//  SIMD, each with its own tile and its own weight stream; the A/B the round-5 review asked for at 8 192 utterances.  LABNOTES round 6.)
+#ifdef WN_EXP_TWO_WG
+__global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), (BT == 1 ? 2 : 1)) void wavenet_wg(const Params p) {
+#else
 __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_wg(const Params p) {
+#endif
     constexpr bool FEAT = RAW == 3;
     constexpr int KFC = FEAT ? feat_kfc<F16>() : 0;
     using C = Cfg<F16, R, S, A, BT, KFC>;
