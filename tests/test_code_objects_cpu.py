@@ -67,3 +67,27 @@ def test_the_conditioning_producer_uses_no_scratch_and_two_waves_fit_a_simd():
         assert scratch == 0 and spill == 0, name
     three = [r for r in rows if "<3>" in r[0].replace(" ", "") or "ILi3E" in r[0]]          # (anonymous-namespace names stay mangled)
     assert three and three[0][1] + three[0][2] <= 256, three          # n_cond = 80: the shape bench.py runs
+
+
+def test_round6_instantiations_exist_and_use_no_scratch():
+    """The kernels round 6 added are in the shipped code objects and spill nothing: four tiles per workgroup (dump-free, packed
+    conditioning) with and without ring slots in LDS, the LR variants of the three-tile kernels for every conditioning path of the fp16
+    engine, the dump-free fp32 kernels behind wavenet_infer(), and the chain instantiation that requests a unit's conditioning up
+    front where stages hold two layers (R = 128)."""
+    if not os.path.exists(os.path.join(BUILD, "inst_64_256_256_p16.o")):
+        pytest.skip("build the library first (__graft_entry__.build())")
+    rows = {r[0].replace(" ", ""): r for r in kernel_table("inst_64_256_256_p16.o")}
+    want = ["wn::wavenet_wg<true,64,256,256,4,%s,false,0,%s>" % (emb, lr) for emb in ("true", "false") for lr in ("true", "false")]
+    want += ["wn::wavenet_wg<true,64,256,256,3,true,false,%d,true>" % raw for raw in (0, 1, 2, 3)]
+    for name in want:
+        assert name in rows, name
+        assert rows[name][4] == 0 and rows[name][5] == 0, rows[name]
+    assert not any(k.startswith("wn::wavenet_wg<true,64,256,256,4,") and ",false,3," in k for k in rows), "no four-tile kernel computes the conditioning itself"
+    rows32 = {r[0].replace(" ", ""): r for r in kernel_table("inst_64_256_256_p32.o")}
+    for name in ("wn::wavenet_wg<false,64,256,256,1,true,false,0,false>", "wn::wavenet_wg<false,64,256,256,1,true,false,0,true>",
+                 "wn::wavenet_chain<false,64,256,256,false,false>"):
+        assert name in rows32, name
+    rows4 = {r[0].replace(" ", ""): r for r in kernel_table("inst_128_256_256_p16.o")}
+    hoist = "wn::wavenet_chain<true,128,256,256,false,true>"
+    assert hoist in rows4 and rows4[hoist][4] == 0 and rows4[hoist][5] == 0, rows4.get(hoist)
+    assert "wn::wavenet_chain<true,64,256,256,false,true>" not in rows, "five-layer stages spill with the hoisted conditioning: not built"
