@@ -164,7 +164,7 @@ def summarise(samples, t0, t1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--wgs", default="1,32,64,128,192,256")
-    ap.add_argument("--bt", default="3", help="tiles per workgroup of the sweep (organisation wg1/wg2/wg3)")
+    ap.add_argument("--bt", default="3", help="tiles per workgroup of the sweep (organisation wg1 / wg2 / wg3 / wg4)")
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--out", default="")
@@ -192,7 +192,7 @@ def main():
         nwg = min(nwg, ncu)
         B = 16 * bt * nwg
         n = args.samples
-        e, N, keep = bench.steady_engine(w, B, n, 11, None if args.mode == "packed" else args.mode, organisation=1 + bt)
+        e, N, keep = bench.steady_engine(w, B, n, 11, None if args.mode == "packed" else args.mode, organisation={1: 2, 2: 3, 3: 4, 4: 10}[bt])
         e.setClockProbe(True)
         info = e.kernelInfo(B, False)
         ms = bench.time_range(e, bench.STEADY_FROM, n, N, B)          # warm
