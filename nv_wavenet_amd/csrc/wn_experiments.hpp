@@ -40,6 +40,12 @@
 #ifndef WN_HEADREGS4
 #define WN_HEADREGS4 0       // ... four tiles per workgroup: the whole head is streamed (428 - 440 registers without it)
 #endif
+#ifndef WN_ZS_B_REGS
+#define WN_ZS_B_REGS 4096    // wavenet_wg head: ... of the A x S GEMM (4096: always in registers)
+#endif
+#ifndef WN_ZA_B_REGS
+#define WN_ZA_B_REGS 128     // wavenet_wg head: the B fragments of the A x A GEMM stay in registers up to this many, else they are read from LDS as they are needed
+#endif
 #ifndef WN_TAKE_G
 #define WN_TAKE_G 1          // wavenet_wg: weight fragments waited for together (take_group); > 1 measured slower
 #endif

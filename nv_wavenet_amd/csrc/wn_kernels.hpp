@@ -205,7 +205,7 @@ struct Cfg {
     // B fragments from LDS as it goes instead of holding all KF_A of them in registers.
     // (also with three tiles per workgroup: the 24 KiB it frees let the current tap's embedding table into LDS)
     static constexpr bool ALIAS_LG = ZSBUF + LGBUF > 100 * 1024 || BT >= 3;
-    static constexpr bool ZA_B_FROM_LDS = KF_A * BT * 4 > 128;
+    static constexpr bool ZA_B_FROM_LDS = KF_A * BT * 4 > WN_ZA_B_REGS;
     static constexpr int OFF_X = 0, OFF_H = OFF_X + XBUF, OFF_SK = OFF_H + HBUF, OFF_ZS = OFF_SK + SKBUF;
     static constexpr int OFF_LG = ALIAS_LG ? OFF_ZS : OFF_ZS + ZSBUF;
     static constexpr int OFF_Y = ALIAS_LG ? OFF_ZS + (ZSBUF > LGBUF ? ZSBUF : LGBUF) : OFF_LG + LGBUF;
@@ -1620,7 +1620,16 @@ __global__ __launch_bounds__((Cfg<F16, R, S, A, BT>::THREADS), 1) void wavenet_w
             }
         wg_barrier();
         floatx4 zs[BT][ATW];
-        {
+        if constexpr (HS != 0 && KF_S * BT * 4 > WN_ZS_B_REGS) {
+            // (the B fragments of the A x S GEMM read from their LDS image as they are needed: four tiles' 32 fragments do not fit the
+            //  register file beside the accumulators)
+#pragma unroll
+            for (int bt = 0; bt < BT; bt++)
+#pragma unroll
+                for (int i = 0; i < ATW; i++) zs[bt][i] = *(const floatx4*)(headBias + (w + NW * i) * 16 + g * 4);
+            gemm_ldsb_b<F16, PF, C::HSP, BT, ATW, KF_S>(ws, rsW, C::O_ZS, L * FLW, 0, laneOff, zs, skbuf, lane);
+            skip_frags<F16, PF, C::HSP, ws_pin, C::PAD1>(ws, rsW, C::FW_ZS, L * FLW, 0, laneOff);   // (zero fragments)
+        } else {
             frag sb[BT][KF_S];
 #pragma unroll
             for (int bt = 0; bt < BT; bt++) {
